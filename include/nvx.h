@@ -1,0 +1,193 @@
+/*
+ * nvx.h -- C ABI of libnvx_hip.so: the MI355X (gfx950) kernels behind the paged-attention +
+ * radix KV-cache path of nano-vllm-x.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers and sizes only; device pointers unless the name says `host`;
+ *   - the caller owns all memory; nothing here allocates, frees or synchronises;
+ *   - work is launched on `stream` (a hipStream_t passed as void*), so every call can be
+ *     captured into a hipGraph;
+ *   - return 0 on success, a negative NVX_E* code otherwise; nvx_last_error() gives the text.
+ *     The Python host raises RuntimeError on a non-zero code, which is how the reference
+ *     reports failures on this path (nanovllmx/core/kv_cache.py:327, asserts at :39-42).
+ *   - 16-bit floating point means bfloat16 (the dtype of the Qwen3 checkpoints the reference
+ *     serves, nanovllmx/core/model_runner.py:38-39).
+ *   - head_dim is 128 (all Qwen3 sizes); other values are rejected with NVX_EUNSUPPORTED.
+ *
+ * The reference has no FFI of its own: its operator surface is the set of Python classes in
+ * nanovllmx/core/kv_cache.py and nanovllmx/layers/{attention,layernorm,rotary_embedding,
+ * sampler,activation}.py.  Each entry point below names the reference call it stands behind.
+ */
+#ifndef NVX_H
+#define NVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVX_OK 0
+#define NVX_EINVAL (-1)       /* bad argument (null pointer, negative size, misalignment) */
+#define NVX_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define NVX_ELAUNCH (-3)      /* the HIP runtime refused the launch */
+#define NVX_ENOSPACE (-4)     /* caller-provided workspace too small */
+
+typedef void* nvx_stream_t;
+
+/* Library identification and diagnostics. */
+int nvx_abi_version(void);
+const char* nvx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * KV scatter.  Replaces store_kvcache / store_kvcache_kernel
+ * (nanovllmx/core/kv_cache.py:12-44, called from layers/attention.py:347-352).
+ * Row i of k and v (row_elems = num_kv_heads*head_dim contiguous 16-bit elements, rows
+ * k_row_stride / v_row_stride elements apart) is copied to row slots[i] of k_cache / v_cache
+ * (rows row_elems apart).  slots[i] == -1 skips the row.  Bit-exact copy.
+ * row_elems must be a multiple of 8; all row bases 16-byte aligned. */
+int nvx_store_kv(const void* k, const void* v, int64_t k_row_stride, int64_t v_row_stride,
+                 void* k_cache, void* v_cache, const int64_t* slots, int64_t n_tokens,
+                 int64_t row_elems, int64_t n_slots, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RMSNorm.  Replaces RMSNorm.forward (nanovllmx/layers/layernorm.py:17-36).
+ * x: (rows, hidden) bf16, rows x_row_stride elements apart; weight: (hidden) bf16 or fp32
+ * (weight_is_f32); y: (rows, hidden) bf16 contiguous.
+ * With residual != NULL: acc = x + residual in fp32, residual_out = bf16(acc), and the
+ * normalisation consumes the unrounded acc (layernorm.py:26-31).  residual_out may alias
+ * residual, y may alias x.  hidden must be a multiple of 8 and <= 8192. */
+int nvx_rmsnorm(const void* x, int64_t x_row_stride, const void* residual, const void* weight,
+                int weight_is_f32, void* y, void* residual_out, int64_t rows, int64_t hidden,
+                float eps, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Rotary embedding.  Replaces RotaryEmbedding.forward
+ * (nanovllmx/layers/rotary_embedding.py:74-102) for rotary_dim == head_dim == 128.
+ * cos_sin: fp32 (max_pos, 128) = [cos(64) | sin(64)]; positions int64 (n_tokens).
+ * Input halves (j, j+64) are paired and the result is written interleaved (2j, 2j+1); cos/sin
+ * are rounded to bf16 first and every product and sum is rounded to bf16, as eager bf16
+ * arithmetic does (rotary_embedding.py:16-24).  q: (n_tokens, n_q_heads*128) rows q_row_stride
+ * elements apart, likewise k; outputs contiguous.  Outputs may alias inputs. */
+int nvx_rope(const int64_t* positions, const float* cos_sin, int64_t max_pos,
+             const void* q, int64_t q_row_stride, const void* k, int64_t k_row_stride,
+             void* q_out, void* k_out, int64_t n_tokens, int n_q_heads, int n_kv_heads,
+             nvx_stream_t stream);
+
+/* Fused per-head RMSNorm(q), RMSNorm(k), rotary, and KV scatter: what
+ * Qwen3Attention.forward does between the QKV projection and the attention call
+ * (nanovllmx/models/qwen3.py:123-133 followed by layers/attention.py:344-352), one launch.
+ * qkv: (n_tokens, (n_q_heads + 2*n_kv_heads)*128) bf16, rows qkv_row_stride apart.
+ * q_out: (n_tokens, n_q_heads*128) contiguous.  Normalised+rotated k and raw v of token i go
+ * to row slots[i] of k_cache / v_cache ((n_slots, n_kv_heads, 128)); slots[i] == -1 skips.
+ * Intermediate roundings are those of the unfused reference ops. */
+int nvx_qknorm_rope_store(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+                          const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
+                          const void* k_norm_weight, float eps, const int64_t* slots,
+                          void* q_out, void* k_cache, void* v_cache, int64_t n_slots,
+                          int64_t n_tokens, int n_q_heads, int n_kv_heads, nvx_stream_t stream);
+
+/* SiluAndMul.  Replaces SiluAndMul.forward (nanovllmx/layers/activation.py:15-18).
+ * x: (rows, 2*d) bf16 contiguous -> y: (rows, d) = bf16(bf16(silu(x[:, :d])) * x[:, d:]). */
+int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Paged attention, decode: one query token per sequence.  Replaces
+ * BatchDecodeWithPagedKVCacheWrapper.plan/run as called from
+ * nanovllmx/layers/attention.py:120-132,197-207,277-288 (plan) and :365-369 (run),
+ * page size 1, NHD layout.
+ *
+ * Block table: sequence b owns the slots kv_indices[kv_start[b] .. kv_start[b]+kv_len[b]).
+ * A CSR table (attention.py:84-101) is the case kv_start = indptr[:-1], kv_len = diff(indptr).
+ *
+ * nvx_decode_plan splits every sequence into chunks of one common length so that the launch
+ * fills the chip, and writes the work list into plan_ws (int32, >= nvx_decode_plan_ws_ints()).
+ * It runs on the device (no host sync) and is part of the captured graph; call it once per
+ * step, then nvx_paged_decode once per layer.
+ *
+ * nvx_paged_decode: q (batch, n_q_heads, 128) bf16 rows q_row_stride apart; k_cache/v_cache
+ * (n_slots, n_kv_heads, 128) bf16 of one layer; out (batch, n_q_heads, 128) bf16 contiguous.
+ * softmax(q.k * sm_scale) in fp32.  partial_ws: fp32 scratch for split sequences,
+ * >= nvx_decode_partial_ws_floats() floats.  Rows with kv_len <= 0 produce zeros. */
+int64_t nvx_decode_plan_ws_ints(int64_t max_batch, int n_kv_heads);
+int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads, int n_kv_heads);
+int nvx_decode_plan(const int32_t* kv_len, int64_t batch, int n_kv_heads, int32_t* plan_ws,
+                    int64_t plan_ws_ints, nvx_stream_t stream);
+int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                     int64_t n_slots, const int32_t* kv_indices, const int64_t* kv_start,
+                     const int32_t* kv_len, const int32_t* plan_ws, float* partial_ws,
+                     void* out, int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale,
+                     nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Paged attention, prefill: causal, variable-length, queries right-aligned to the keys.
+ * Replaces BatchPrefillWithPagedKVCacheWrapper.plan/run as called from
+ * nanovllmx/layers/attention.py:104-119 and :360-364.
+ * q: (n_tokens, n_q_heads, 128) rows q_row_stride apart; sequence b owns query rows
+ * qo_indptr[b]..qo_indptr[b+1] and the slots kv_indices[kv_indptr[b]..kv_indptr[b+1]);
+ * query i of a sequence with Lq queries and Lkv keys sees keys 0 .. i + (Lkv - Lq).
+ * plan_ws: int32 scratch >= nvx_prefill_plan_ws_ints(batch); filled by nvx_prefill_plan
+ * (device side, no sync).  MFMA (bf16 in, fp32 accumulate) for QK^T and PV. */
+int64_t nvx_prefill_plan_ws_ints(int64_t batch);
+int nvx_prefill_plan(const int32_t* qo_indptr, int64_t batch, int32_t* plan_ws,
+                     int64_t plan_ws_ints, nvx_stream_t stream);
+int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                      int64_t n_slots, const int32_t* qo_indptr, const int32_t* kv_indptr,
+                      const int32_t* kv_indices, const int32_t* plan_ws, void* out,
+                      int64_t n_tokens, int64_t batch, int n_q_heads, int n_kv_heads,
+                      float sm_scale, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sampler.  Replaces Sampler.forward with all four parameter tensors present
+ * (nanovllmx/layers/sampler.py:39-55, as called from core/model_runner.py:266-272).
+ * logits: (batch, vocab) bf16 or fp32 (logits_is_f32), rows logits_row_stride apart.
+ * Per row: x = logits / temperature; top-k keeps x >= (k-th largest x); top-p drops the
+ * longest ascending prefix whose softmax mass is <= 1 - top_p (never the maximum); min-p
+ * drops softmax(x) < min_p * max; the token is drawn from softmax of what is left.
+ * The draw uses Philox4x32-10(seed, offset) Gumbel noise per (row, token): exact in
+ * distribution, reproducible for a given (seed, offset), not bit-comparable with
+ * torch.multinomial.  out_ids: int64 (batch).  Equal scores are ordered by token id wherever the
+ * reference's sort order decides (top-p boundary), as a stable ascending sort does.
+ * No sort and no scratch memory: thresholds come from radix selection over the row.
+ * nvx_sampler_probs writes the masked, renormalised distribution itself (fp32 (batch, vocab)):
+ * the part of the reference computation that is comparable up to fp32 rounding. */
+int nvx_sample(const void* logits, int logits_is_f32, int64_t logits_row_stride,
+               const float* temperatures, const int64_t* top_ks, const float* top_ps,
+               const float* min_ps, int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset,
+               int64_t* out_ids, nvx_stream_t stream);
+int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_stride,
+                      const float* temperatures, const int64_t* top_ks, const float* top_ps,
+                      const float* min_ps, int64_t batch, int64_t vocab, float* probs_out,
+                      nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Device-resident block table for graph-replayed decode steps.  Replaces the per-step rebuild
+ * of the CSR buffers and model inputs from Python lists in
+ * AttentionBackend.build_metadata_for_cuda_graph_replay (nanovllmx/layers/attention.py:219-275)
+ * and ModelRunner.prepare_input (core/model_runner.py:175-189) with an incremental update
+ * driven by one small host-to-device copy per step.
+ *
+ * table: int32 (n_rows, row_capacity); a running sequence keeps one row for its lifetime.
+ *
+ * nvx_block_table_write_rows (after a prefill): for b < batch copies
+ * kv_indices[kv_indptr[b] .. kv_indptr[b+1]) into table[rows[b]][0 ..).
+ *
+ * nvx_decode_step_setup (first node of a decode graph): `step` is the int32 buffer the host
+ * uploaded: step[0] = batch (live rows, <= padded_batch), then four arrays of `stride` entries
+ * starting at step[4]: row, pos, slot, token.  For i < batch:
+ *   table[row[i]][pos[i]] = slot[i]; kv_start[i] = row[i]*row_capacity; kv_len[i] = pos[i]+1;
+ *   out_slots[i] = slot[i]; positions[i] = pos[i]; input_ids[i] = token[i].
+ * For batch <= i < padded_batch (padding rows of a captured graph, attention.py:240-265):
+ *   kv_start[i] = pad_start, kv_len[i] = 1, out_slots[i] = -1, positions[i] = input_ids[i] = 0. */
+int nvx_block_table_write_rows(const int32_t* kv_indices, const int32_t* kv_indptr,
+                               const int32_t* rows, int64_t batch, int32_t* table, int64_t n_rows,
+                               int64_t row_capacity, nvx_stream_t stream);
+int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_batch,
+                          int32_t* table, int64_t n_rows, int64_t row_capacity, int64_t pad_start,
+                          int64_t* kv_start, int32_t* kv_len, int64_t* out_slots,
+                          int64_t* positions, int64_t* input_ids, nvx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVX_H */

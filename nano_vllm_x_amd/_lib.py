@@ -1,0 +1,72 @@
+"""ctypes binding of libnvx_hip.so (the C ABI declared in include/nvx.h).
+
+The library is the product: if it is missing or fails to load, importing anything that computes
+raises -- there is no CPU or PyTorch fallback on this path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvx_hip.so")
+
+_c_i64, _c_i32, _c_f32, _c_vp, _c_u64 = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/nvx.h one to one
+SIGNATURES = {
+    "nvx_abi_version": (_c_i32, []),
+    "nvx_last_error": (ctypes.c_char_p, []),
+    "nvx_store_kv": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "nvx_rmsnorm": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_i64, _c_i64, _c_f32, _c_vp]),
+    "nvx_rope": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_vp]),
+    "nvx_qknorm_rope_store": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp, _c_vp,
+                                       _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_vp]),
+    "nvx_silu_mul": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    "nvx_decode_plan_ws_ints": (_c_i64, [_c_i64, _c_i32]),
+    "nvx_decode_partial_ws_floats": (_c_i64, [_c_i64, _c_i32, _c_i32]),
+    "nvx_decode_plan": (_c_i32, [_c_vp, _c_i64, _c_i32, _c_vp, _c_i64, _c_vp]),
+    "nvx_paged_decode": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64,
+                                  _c_i32, _c_i32, _c_f32, _c_vp]),
+    "nvx_prefill_plan_ws_ints": (_c_i64, [_c_i64]),
+    "nvx_prefill_plan": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp]),
+    "nvx_paged_prefill": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
+                                   _c_i32, _c_i32, _c_f32, _c_vp]),
+    "nvx_sample": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_vp]),
+    "nvx_sampler_probs": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
+    "nvx_block_table_write_rows": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp]),
+    "nvx_decode_step_setup": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+}
+
+_lib = None
+
+
+class NvxLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NvxLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C nano_vllm_x_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NvxLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().nvx_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'nvx'} failed ({rc}): {msg}")

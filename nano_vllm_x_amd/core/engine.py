@@ -1,0 +1,97 @@
+"""Step loop: schedule -> run the model -> fold the sampled tokens back into the sequences.
+
+`EngineCore` is the model-free half (admission, finish rules; nanovllmx/core/engine.py:50-79,
+119-154); `Engine` adds the in-process model runner and `step()` (engine.py:81-100).  The reference
+spreads this over an engine process and one worker process per GPU joined by pickled queues
+(engine_client.py, executor.py, worker_client.py); here every rank runs the same deterministic loop
+in its own process (SPMD), so a step needs no host-side message at all -- only the collectives inside
+the model and one broadcast of the sampled ids.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from .common import EngineOutput, FinishReason, ForwardBatch, SamplingParams, Sequence
+from .scheduler import Scheduler
+
+
+class EngineCore:
+    def __init__(self, kv_cache_size: int, max_bs: int, context_len: int = 2048):
+        self.context_len = context_len
+        self.scheduler = Scheduler(kv_cache_size=kv_cache_size, max_bs=max_bs)
+
+    def add_sequence(self, sequence_id: str, prompt_token_ids: list, sampling_params: SamplingParams):
+        if len(prompt_token_ids) > self.context_len:   # keep the tail (engine.py:59-60)
+            prompt_token_ids = prompt_token_ids[-self.context_len:]
+        n = len(prompt_token_ids)
+        self.scheduler.add_sequence(Sequence(seq_id=sequence_id, token_ids=prompt_token_ids, num_tokens=n,
+                                             prompt_len=n, sampling_params=sampling_params))
+
+    def abort_sequence(self, sequence_id: str):
+        seq = self.scheduler.get_sequence(sequence_id)
+        if seq is not None:
+            self.scheduler.finish_sequence(seq)
+
+    def has_unfinished_sequences(self) -> bool:
+        return self.scheduler.has_unfinished_sequences()
+
+    @staticmethod
+    def _is_sequence_finished(seq: Sequence):
+        """Stop rules in the reference's order (engine.py:143-154).  NB `max_tokens` caps the TOTAL
+        length, prompt included."""
+        sp = seq.sampling_params
+        if not sp.ignore_eos and seq.token_ids[-1] == sp.eos_token_id:
+            return True, FinishReason.STOP
+        if sp.max_tokens and seq.num_tokens >= sp.max_tokens:
+            return True, FinishReason.LENGTH
+        if sp.max_new_tokens and seq.num_tokens >= seq.prompt_len + sp.max_new_tokens:
+            return True, FinishReason.LENGTH
+        return False, None
+
+    def update_from_output(self, batch: ForwardBatch, output_ids: list) -> list:
+        outs = []
+        sched = self.scheduler
+        for seq, tok in zip(batch.seqs, output_ids):
+            sched.update_sequence(seq, tok)
+            done, why = self._is_sequence_finished(seq)
+            if done:
+                sched.finish_sequence(seq)
+            outs.append(EngineOutput(seq_id=seq.seq_id, new_token_id=tok, is_finished=done, finish_reason=why,
+                                     num_prompt_tokens=seq.prompt_len,
+                                     num_generated_tokens=seq.num_tokens - seq.prompt_len))
+        return outs
+
+
+class Engine(EngineCore):
+    """Engine with the reference's nine constructor arguments (engine.py:13-24, llm.py:17-28)."""
+
+    def __init__(self, model: str, gpu_memory_utilization: float, max_bs: int, tp_size: int = 1, pp_size: int = 1,
+                 nccl_port: int = 29500, device_ids: Optional[list] = None, enforce_eager: bool = False,
+                 context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0):
+        from .model_runner import ModelRunner
+
+        if pp_size != 1:
+            raise NotImplementedError("pipeline parallelism is outside the hot path built here (tp only)")
+        self.model_runner = ModelRunner(model=model, max_bs=max_bs, tp_size=tp_size, nccl_port=nccl_port,
+                                        device_ids=device_ids, enforce_eager=enforce_eager, context_len=context_len,
+                                        seed=seed)
+        self.model_runner.load_model()
+        if kv_cache_size is None:
+            kv_cache_size = self.model_runner.profile_kv_cache_size(gpu_memory_utilization)
+        self.kv_cache_size = kv_cache_size
+        self.model_runner.initialize_kv_cache(kv_cache_size)
+        super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len)
+        self.scheduler.on_release = self.model_runner.release_sequence
+
+    def step(self) -> list:
+        batch = self.scheduler.schedule()
+        if not batch:
+            return []
+        output_ids = self.model_runner.execute_model(batch)
+        return self.update_from_output(batch, output_ids)
+
+    def wait_until_ready(self):
+        return True
+
+    def shutdown(self):
+        self.model_runner.shutdown()

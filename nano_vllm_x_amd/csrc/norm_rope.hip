@@ -1,0 +1,291 @@
+// RMSNorm, rotary embedding, fused qk-norm + rotary + KV scatter, SiluAndMul.
+// All four are HBM-bound streaming kernels: 16-byte loads/stores per lane, fp32 math in registers,
+// wave64 shuffles for the row reductions, no LDS.
+#include "nvx_dev.h"
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row, the row stays in registers between the two passes.
+// ---------------------------------------------------------------------------------------------
+template <int ITERS, bool HAS_RES, bool W_F32>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(
+    const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* residual, const void* __restrict__ weight,
+    uint16_t* y, uint16_t* residual_out, int64_t rows, int hidden, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* xr = x + row * x_stride;
+    float v[ITERS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int col = it * 512 + lane * 8;
+        if (col < hidden) {
+            const uint4 a = *reinterpret_cast<const uint4*>(xr + col);
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            if (HAS_RES) {
+                const uint4 r = *reinterpret_cast<const uint4*>(residual + row * hidden + col);
+                const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bf16lo_to_f32(aw[j]) + bf16lo_to_f32(rw[j]);
+                    const float hi = bf16hi_to_f32(aw[j]) + bf16hi_to_f32(rw[j]);
+                    v[it][2 * j] = lo;
+                    v[it][2 * j + 1] = hi;
+                    ow[j] = pack_bf16x2(lo, hi);
+                }
+                *reinterpret_cast<uint4*>(residual_out + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[it][2 * j] = bf16lo_to_f32(aw[j]);
+                    v[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int col = it * 512 + lane * 8;
+        if (col < hidden) {
+            float w[8];
+            if (W_F32) {
+                const float4 w0 = *reinterpret_cast<const float4*>((const float*)weight + col);
+                const float4 w1 = *reinterpret_cast<const float4*>((const float*)weight + col + 4);
+                w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+                w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+            } else {
+                const uint4 wv = *reinterpret_cast<const uint4*>((const uint16_t*)weight + col);
+                const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { w[2 * j] = bf16lo_to_f32(ww[j]); w[2 * j + 1] = bf16hi_to_f32(ww[j]); }
+            }
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ow[j] = pack_bf16x2((v[it][2 * j] * inv) * w[2 * j], (v[it][2 * j + 1] * inv) * w[2 * j + 1]);
+            *reinterpret_cast<uint4*>(y + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+template <int ITERS>
+static void launch_rmsnorm(const void* x, int64_t xs, const void* res, const void* w, int wf32, void* y, void* ro,
+                           int64_t rows, int hidden, float eps, hipStream_t st) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define NVX_RMS(HR, WF) hipLaunchKernelGGL((rmsnorm_kernel<ITERS, HR, WF>), grid, block, 0, st, (const uint16_t*)x, xs, \
+        (const uint16_t*)res, w, (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps)
+    if (res) { if (wf32) NVX_RMS(true, true); else NVX_RMS(true, false); }
+    else     { if (wf32) NVX_RMS(false, true); else NVX_RMS(false, false); }
+#undef NVX_RMS
+}
+
+extern "C" int nvx_rmsnorm(const void* x, int64_t x_row_stride, const void* residual, const void* weight,
+                           int weight_is_f32, void* y, void* residual_out, int64_t rows, int64_t hidden,
+                           float eps, nvx_stream_t stream) {
+    NVX_REQUIRE(rows >= 0 && hidden > 0, NVX_EINVAL, "nvx_rmsnorm: bad size");
+    if (rows == 0) return NVX_OK;
+    NVX_REQUIRE(x && weight && y, NVX_EINVAL, "nvx_rmsnorm: null pointer");
+    NVX_REQUIRE(!residual || residual_out, NVX_EINVAL, "nvx_rmsnorm: residual without residual_out");
+    NVX_REQUIRE(hidden % 8 == 0 && hidden <= 8192 && x_row_stride % 8 == 0 && x_row_stride >= hidden,
+                NVX_EUNSUPPORTED, "nvx_rmsnorm: hidden must be a multiple of 8, <= 8192 (got %lld)", (long long)hidden);
+    NVX_REQUIRE(nvx_aligned16(x) && nvx_aligned16(y) && nvx_aligned16(weight) &&
+                (!residual || (nvx_aligned16(residual) && nvx_aligned16(residual_out))),
+                NVX_EINVAL, "nvx_rmsnorm: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int h = (int)hidden;
+    if (h <= 512) launch_rmsnorm<1>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    else if (h <= 1024) launch_rmsnorm<2>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    else if (h <= 2048) launch_rmsnorm<4>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    else if (h <= 4096) launch_rmsnorm<8>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    else if (h <= 5120) launch_rmsnorm<10>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    else launch_rmsnorm<16>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+    return nvx_check_launch("nvx_rmsnorm");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rotary helpers.  A 128-wide head row is handled by 16 lanes; lane l holds elements 4l..4l+3 of
+// the first half (x1) and 64+4l..64+4l+3 of the second half (x2) and produces the interleaved
+// outputs 8l..8l+7 = (o1_0, o2_0, o1_1, o2_1, ...): one 16-byte store.
+// ---------------------------------------------------------------------------------------------
+struct HalfQuad { float a[4]; float b[4]; };
+
+__device__ __forceinline__ HalfQuad load_half_quads(const uint16_t* row, int l16) {
+    const uint2 p = *reinterpret_cast<const uint2*>(row + 4 * l16);
+    const uint2 q = *reinterpret_cast<const uint2*>(row + 64 + 4 * l16);
+    HalfQuad h;
+    h.a[0] = bf16lo_to_f32(p.x); h.a[1] = bf16hi_to_f32(p.x); h.a[2] = bf16lo_to_f32(p.y); h.a[3] = bf16hi_to_f32(p.y);
+    h.b[0] = bf16lo_to_f32(q.x); h.b[1] = bf16hi_to_f32(q.x); h.b[2] = bf16lo_to_f32(q.y); h.b[3] = bf16hi_to_f32(q.y);
+    return h;
+}
+
+// Eager bf16 arithmetic: cos/sin rounded to bf16, every product and sum rounded to bf16.
+__device__ __forceinline__ uint4 rotate_interleave(const HalfQuad& x, const float* cs_row, int l16) {
+    const float4 c4 = *reinterpret_cast<const float4*>(cs_row + 4 * l16);
+    const float4 s4 = *reinterpret_cast<const float4*>(cs_row + 64 + 4 * l16);
+    const float c[4] = {round_bf16(c4.x), round_bf16(c4.y), round_bf16(c4.z), round_bf16(c4.w)};
+    const float s[4] = {round_bf16(s4.x), round_bf16(s4.y), round_bf16(s4.z), round_bf16(s4.w)};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float o1 = round_bf16(x.a[j] * c[j]) - round_bf16(x.b[j] * s[j]);
+        const float o2 = round_bf16(x.b[j] * c[j]) + round_bf16(x.a[j] * s[j]);
+        o[j] = pack_bf16x2(o1, o2);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__device__ __forceinline__ int64_t clamp_pos(int64_t p, int64_t max_pos) {
+    return p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+}
+
+__global__ __launch_bounds__(256) void rope_kernel(
+    const int64_t* __restrict__ positions, const float* __restrict__ cos_sin, int64_t max_pos,
+    const uint16_t* q, int64_t q_stride, const uint16_t* k, int64_t k_stride, uint16_t* q_out, uint16_t* k_out,
+    int64_t n_tokens, int hq, int hkv) {
+    const int l16 = threadIdx.x & 15;
+    const int heads = hq + hkv;
+    const int64_t rowid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (rowid >= n_tokens * heads) return;
+    const int64_t tok = rowid / heads;
+    const int h = (int)(rowid % heads);
+    const bool is_q = h < hq;
+    const uint16_t* src = is_q ? q + tok * q_stride + h * 128 : k + tok * k_stride + (h - hq) * 128;
+    uint16_t* dst = is_q ? q_out + (tok * hq + h) * 128 : k_out + (tok * hkv + (h - hq)) * 128;
+    const HalfQuad x = load_half_quads(src, l16);
+    const float* cs = cos_sin + clamp_pos(positions[tok], max_pos) * 128;
+    const uint4 o = rotate_interleave(x, cs, l16);
+    *reinterpret_cast<uint4*>(dst + 8 * l16) = o;
+}
+
+extern "C" int nvx_rope(const int64_t* positions, const float* cos_sin, int64_t max_pos, const void* q,
+                        int64_t q_row_stride, const void* k, int64_t k_row_stride, void* q_out, void* k_out,
+                        int64_t n_tokens, int n_q_heads, int n_kv_heads, nvx_stream_t stream) {
+    NVX_REQUIRE(n_tokens >= 0 && n_q_heads >= 0 && n_kv_heads >= 0 && max_pos > 0, NVX_EINVAL, "nvx_rope: bad size");
+    if (n_tokens == 0 || n_q_heads + n_kv_heads == 0) return NVX_OK;
+    NVX_REQUIRE(positions && cos_sin, NVX_EINVAL, "nvx_rope: null pointer");
+    NVX_REQUIRE((n_q_heads == 0 || (q && q_out)) && (n_kv_heads == 0 || (k && k_out)), NVX_EINVAL, "nvx_rope: null pointer");
+    NVX_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0, NVX_EUNSUPPORTED, "nvx_rope: row strides must be multiples of 8");
+    NVX_REQUIRE(nvx_aligned16(q) && nvx_aligned16(k) && nvx_aligned16(q_out) && nvx_aligned16(k_out) && nvx_aligned16(cos_sin),
+                NVX_EINVAL, "nvx_rope: pointers must be 16-byte aligned");
+    const int64_t rows = n_tokens * (n_q_heads + n_kv_heads);
+    const unsigned blocks = (unsigned)((rows + 15) / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, positions, cos_sin, max_pos,
+                       (const uint16_t*)q, q_row_stride, (const uint16_t*)k, k_row_stride, (uint16_t*)q_out,
+                       (uint16_t*)k_out, n_tokens, n_q_heads, n_kv_heads);
+    return nvx_check_launch("nvx_rope");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused: per-head RMSNorm of q and k, rotary, q -> contiguous buffer, k/v -> paged cache rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
+    const uint16_t* __restrict__ qkv, int64_t qkv_stride, const int64_t* __restrict__ positions,
+    const float* __restrict__ cos_sin, int64_t max_pos, const uint16_t* __restrict__ qw, const uint16_t* __restrict__ kw,
+    float eps, const int64_t* __restrict__ slots, uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+    uint16_t* __restrict__ v_cache, int64_t n_slots, int64_t n_tokens, int hq, int hkv) {
+    const int l16 = threadIdx.x & 15;
+    const int heads = hq + 2 * hkv;
+    const int64_t rowid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (rowid >= n_tokens * heads) return;
+    const int64_t tok = rowid / heads;
+    const int h = (int)(rowid % heads);
+    const HalfQuad x = load_half_quads(qkv + tok * qkv_stride + (int64_t)h * 128, l16);
+    // the row's sum of squares is computed for every row kind so that the shuffles stay uniform
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss += x.a[j] * x.a[j] + x.b[j] * x.b[j];
+    ss = quarter_sum(ss);
+    const int64_t slot = slots[tok];
+    const bool slot_ok = slot >= 0 && slot < n_slots;
+    if (h >= hq + hkv) {  // v: plain copy into the slot row
+        if (!slot_ok) return;
+        uint16_t* dst = v_cache + (slot * hkv + (h - hq - hkv)) * 128;
+        *reinterpret_cast<uint2*>(dst + 4 * l16) = make_uint2(pack_bf16x2(x.a[0], x.a[1]), pack_bf16x2(x.a[2], x.a[3]));
+        *reinterpret_cast<uint2*>(dst + 64 + 4 * l16) = make_uint2(pack_bf16x2(x.b[0], x.b[1]), pack_bf16x2(x.b[2], x.b[3]));
+        return;
+    }
+    const bool is_q = h < hq;
+    if (!is_q && !slot_ok) return;
+    const uint16_t* w = is_q ? qw : kw;
+    const uint2 wa = *reinterpret_cast<const uint2*>(w + 4 * l16);
+    const uint2 wb = *reinterpret_cast<const uint2*>(w + 64 + 4 * l16);
+    const float wA[4] = {bf16lo_to_f32(wa.x), bf16hi_to_f32(wa.x), bf16lo_to_f32(wa.y), bf16hi_to_f32(wa.y)};
+    const float wB[4] = {bf16lo_to_f32(wb.x), bf16hi_to_f32(wb.x), bf16lo_to_f32(wb.y), bf16hi_to_f32(wb.y)};
+    const float inv = 1.0f / sqrtf(ss / 128.0f + eps);
+    HalfQuad n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // the unfused norm hands bf16 to the rotary op
+        n.a[j] = round_bf16((x.a[j] * inv) * wA[j]);
+        n.b[j] = round_bf16((x.b[j] * inv) * wB[j]);
+    }
+    const float* cs = cos_sin + clamp_pos(positions[tok], max_pos) * 128;
+    const uint4 o = rotate_interleave(n, cs, l16);
+    uint16_t* dst = is_q ? q_out + (tok * hq + h) * 128 : k_cache + (slot * hkv + (h - hq)) * 128;
+    *reinterpret_cast<uint4*>(dst + 8 * l16) = o;
+}
+
+extern "C" int nvx_qknorm_rope_store(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+                                     const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
+                                     const void* k_norm_weight, float eps, const int64_t* slots, void* q_out,
+                                     void* k_cache, void* v_cache, int64_t n_slots, int64_t n_tokens,
+                                     int n_q_heads, int n_kv_heads, nvx_stream_t stream) {
+    NVX_REQUIRE(n_tokens >= 0 && n_q_heads > 0 && n_kv_heads > 0 && max_pos > 0 && n_slots >= 0, NVX_EINVAL,
+                "nvx_qknorm_rope_store: bad size");
+    if (n_tokens == 0) return NVX_OK;
+    NVX_REQUIRE(qkv && positions && cos_sin && q_norm_weight && k_norm_weight && slots && q_out && k_cache && v_cache,
+                NVX_EINVAL, "nvx_qknorm_rope_store: null pointer");
+    NVX_REQUIRE(qkv_row_stride % 8 == 0 && qkv_row_stride >= (int64_t)(n_q_heads + 2 * n_kv_heads) * 128, NVX_EINVAL,
+                "nvx_qknorm_rope_store: bad qkv row stride");
+    NVX_REQUIRE(nvx_aligned16(qkv) && nvx_aligned16(q_out) && nvx_aligned16(k_cache) && nvx_aligned16(v_cache) &&
+                nvx_aligned16(cos_sin) && nvx_aligned16(q_norm_weight) && nvx_aligned16(k_norm_weight),
+                NVX_EINVAL, "nvx_qknorm_rope_store: pointers must be 16-byte aligned");
+    const int64_t rows = n_tokens * (n_q_heads + 2 * n_kv_heads);
+    const unsigned blocks = (unsigned)((rows + 15) / 16);
+    hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       qkv_row_stride, positions, cos_sin, max_pos, (const uint16_t*)q_norm_weight,
+                       (const uint16_t*)k_norm_weight, eps, slots, (uint16_t*)q_out, (uint16_t*)k_cache,
+                       (uint16_t*)v_cache, n_slots, n_tokens, n_q_heads, n_kv_heads);
+    return nvx_check_launch("nvx_qknorm_rope_store");
+}
+
+// ---------------------------------------------------------------------------------------------
+// SiluAndMul
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_bf16(float x) { return round_bf16(x / (1.0f + __expf(-x))); }
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       int64_t rows, int d8) {
+    const int64_t total = rows * d8;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int64_t r = id / d8;
+        const int c = (int)(id % d8);
+        const uint4 g = *reinterpret_cast<const uint4*>(x + (r * 2 * d8 + c) * 8);
+        const uint4 u = *reinterpret_cast<const uint4*>(x + (r * 2 * d8 + d8 + c) * 8);
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(silu_bf16(bf16lo_to_f32(gw[j])) * bf16lo_to_f32(uw[j]),
+                               silu_bf16(bf16hi_to_f32(gw[j])) * bf16hi_to_f32(uw[j]));
+        *reinterpret_cast<uint4*>(y + id * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream) {
+    NVX_REQUIRE(rows >= 0 && d > 0, NVX_EINVAL, "nvx_silu_mul: bad size");
+    if (rows == 0) return NVX_OK;
+    NVX_REQUIRE(x && y, NVX_EINVAL, "nvx_silu_mul: null pointer");
+    NVX_REQUIRE(d % 8 == 0, NVX_EUNSUPPORTED, "nvx_silu_mul: d must be a multiple of 8");
+    NVX_REQUIRE(nvx_aligned16(x) && nvx_aligned16(y), NVX_EINVAL, "nvx_silu_mul: pointers must be 16-byte aligned");
+    const int64_t total = rows * (d / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, rows, (int)(d / 8));
+    return nvx_check_launch("nvx_silu_mul");
+}

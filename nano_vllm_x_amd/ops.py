@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/nvx.h).
+
+PyTorch is used here only as the owner of device memory and of the current HIP stream; every
+function validates shapes on the host (a kernel that is handed a wrong shape faults the GPU), then
+makes exactly one call into libnvx_hip.so on `torch.cuda.current_stream()`, which makes all of them
+capturable into a hipGraph.  The same functions are registered as `torch.ops.nvx.*` custom ops.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(cond: bool, msg: str):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None:
+            _need(t.is_cuda, "nvx ops need device tensors (the HIP path has no CPU fallback)")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------
+def store_kvcache(k, v, k_cache, v_cache, kv_indices):
+    """Same contract as nanovllmx.core.kv_cache.store_kvcache (kv_cache.py:36-44)."""
+    _dev(k, v, k_cache, v_cache, kv_indices)
+    num_tokens, num_heads, head_dim = k.shape
+    row = num_heads * head_dim
+    assert k.stride(-1) == 1 and v.stride(-1) == 1
+    assert k.stride(-2) == head_dim and v.stride(-2) == head_dim
+    assert k_cache.stride(-3) == row and v_cache.stride(-3) == row
+    assert kv_indices.numel() == num_tokens
+    _need(k.dtype == v.dtype == k_cache.dtype == v_cache.dtype and k.element_size() == 2, "store_kvcache: 16-bit dtypes only")
+    _need(kv_indices.dtype == torch.int64 and kv_indices.is_contiguous(), "store_kvcache: kv_indices must be contiguous int64")
+    lib = _lib.load()
+    _lib.check(lib.nvx_store_kv(_ptr(k), _ptr(v), k.stride(0), v.stride(0), _ptr(k_cache), _ptr(v_cache), _ptr(kv_indices),
+                                num_tokens, row, k_cache.shape[-3], _stream()), "nvx_store_kv")
+
+
+def rmsnorm(x, weight, eps, residual=None):
+    """RMSNorm.forward (layernorm.py:17-36): returns y, or (y, new_residual) when residual is given."""
+    _dev(x, weight, residual)
+    _need(x.dtype == BF16, "rmsnorm: bf16 activations only")
+    hidden = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1:
+        x2 = x  # rows may be strided (a split view of a fused projection)
+    else:
+        x = x.contiguous()
+        x2 = x.view(-1, hidden)
+    rows = x2.shape[0]
+    _need(weight.numel() == hidden and weight.is_contiguous(), "rmsnorm: weight shape")
+    _need(weight.dtype in (BF16, torch.float32), "rmsnorm: weight must be bf16 or fp32")
+    y = torch.empty((rows, hidden), dtype=BF16, device=x.device)
+    res_out = None
+    if residual is not None:
+        _need(residual.dtype == BF16 and residual.shape == x.shape, "rmsnorm: residual shape/dtype")
+        residual = residual.contiguous()
+        res_out = torch.empty((rows, hidden), dtype=BF16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_rmsnorm(_ptr(x2), x2.stride(0), _ptr(residual), _ptr(weight), int(weight.dtype == torch.float32),
+                               _ptr(y), _ptr(res_out), rows, hidden, float(eps), _stream()), "nvx_rmsnorm")
+    y = y.view(x.shape)
+    if residual is None:
+        return y
+    return y, res_out.view(x.shape)
+
+
+def rope(positions, q, k, cos_sin_cache, head_size=128):
+    """RotaryEmbedding.forward (rotary_embedding.py:74-102), rotary_dim == head_size == 128."""
+    _dev(positions, q, k, cos_sin_cache)
+    _need(head_size == 128 and cos_sin_cache.shape[-1] == 128 and cos_sin_cache.dtype == torch.float32 and
+          cos_sin_cache.is_contiguous(), "rope: needs an fp32 (max_pos, 128) table")
+    _need(q.dtype == BF16 and k.dtype == BF16, "rope: bf16 only")
+    positions = positions.flatten()
+    _need(positions.dtype == torch.int64 and positions.is_contiguous(), "rope: positions must be int64")
+    t = positions.numel()
+    q2, k2 = q.reshape(t, -1) if q.is_contiguous() else q.view(t, -1), k.reshape(t, -1) if k.is_contiguous() else k.view(t, -1)
+    _need(q2.stride(1) == 1 and k2.stride(1) == 1 and q2.shape[1] % 128 == 0 and k2.shape[1] % 128 == 0, "rope: row layout")
+    q_out = torch.empty((t, q2.shape[1]), dtype=BF16, device=q.device)
+    k_out = torch.empty((t, k2.shape[1]), dtype=BF16, device=k.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_rope(_ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0], _ptr(q2), q2.stride(0), _ptr(k2),
+                            k2.stride(0), _ptr(q_out), _ptr(k_out), t, q2.shape[1] // 128, k2.shape[1] // 128, _stream()),
+               "nvx_rope")
+    return q_out.view(q.shape), k_out.view(k.shape)
+
+
+def qknorm_rope_store(qkv, positions, cos_sin_cache, q_norm_weight, k_norm_weight, eps, slots, k_cache, v_cache,
+                      n_q_heads, n_kv_heads, q_out=None):
+    """qwen3.py:123-133 + attention.py:344-352 in one launch.  Returns q (T, n_q_heads*128)."""
+    _dev(qkv, positions, cos_sin_cache, q_norm_weight, k_norm_weight, slots, k_cache, v_cache)
+    t = qkv.shape[0]
+    width = (n_q_heads + 2 * n_kv_heads) * 128
+    _need(qkv.dim() == 2 and qkv.shape[1] == width and qkv.stride(1) == 1 and qkv.dtype == BF16, "qknorm_rope_store: qkv layout")
+    _need(positions.dtype == torch.int64 and positions.numel() >= t and positions.is_contiguous(), "qknorm_rope_store: positions")
+    _need(slots.dtype == torch.int64 and slots.numel() >= t and slots.is_contiguous(), "qknorm_rope_store: slots")
+    _need(k_cache.shape[-2:] == (n_kv_heads, 128) and v_cache.shape == k_cache.shape and k_cache.is_contiguous() and
+          v_cache.is_contiguous() and k_cache.dtype == BF16, "qknorm_rope_store: cache layout")
+    _need(q_norm_weight.dtype == BF16 and k_norm_weight.dtype == BF16 and q_norm_weight.numel() == 128 and
+          k_norm_weight.numel() == 128, "qknorm_rope_store: norm weights must be bf16 (128)")
+    _need(cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[-1] == 128 and cos_sin_cache.is_contiguous(), "qknorm_rope_store: table")
+    if q_out is None:
+        q_out = torch.empty((t, n_q_heads * 128), dtype=BF16, device=qkv.device)
+    else:
+        _need(q_out.shape == (t, n_q_heads * 128) and q_out.is_contiguous() and q_out.dtype == BF16, "qknorm_rope_store: q_out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_qknorm_rope_store(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
+                                         _ptr(q_norm_weight), _ptr(k_norm_weight), float(eps), _ptr(slots), _ptr(q_out),
+                                         _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], t, n_q_heads, n_kv_heads, _stream()),
+               "nvx_qknorm_rope_store")
+    return q_out
+
+
+def silu_mul(x, out=None):
+    """SiluAndMul.forward (activation.py:15-18)."""
+    _dev(x)
+    _need(x.dtype == BF16 and x.is_contiguous(), "silu_mul: contiguous bf16 only")
+    d = x.shape[-1] // 2
+    rows = x.numel() // (2 * d)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (d,), dtype=BF16, device=x.device)
+    else:
+        _need(out.is_contiguous() and out.numel() == rows * d and out.dtype == BF16, "silu_mul: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_silu_mul(_ptr(x), _ptr(out), rows, d, _stream()), "nvx_silu_mul")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+class DecodeWorkspace:
+    """Caller-owned scratch of the decode attention (plan list + split partials), sized once."""
+
+    def __init__(self, max_batch: int, n_q_heads: int, n_kv_heads: int, device):
+        lib = _lib.load()
+        self.max_batch, self.n_q_heads, self.n_kv_heads = max_batch, n_q_heads, n_kv_heads
+        self.plan = torch.zeros(lib.nvx_decode_plan_ws_ints(max_batch, n_kv_heads), dtype=torch.int32, device=device)
+        self.partial = torch.empty(lib.nvx_decode_partial_ws_floats(max_batch, n_q_heads, n_kv_heads), dtype=torch.float32,
+                                   device=device)
+
+
+def decode_plan(kv_len, ws: DecodeWorkspace):
+    _dev(kv_len)
+    b = kv_len.numel()
+    _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and 0 < b <= ws.max_batch, "decode_plan: kv_len")
+    lib = _lib.load()
+    _lib.check(lib.nvx_decode_plan(_ptr(kv_len), b, ws.n_kv_heads, _ptr(ws.plan), ws.plan.numel(), _stream()), "nvx_decode_plan")
+
+
+def paged_decode(q, k_cache, v_cache, kv_indices, kv_start, kv_len, ws: DecodeWorkspace, sm_scale, out=None):
+    """q (B, Hq*128) or (B, Hq, 128); caches (slots, Hkv, 128) of one layer; plan must be current."""
+    _dev(q, k_cache, v_cache, kv_indices, kv_start, kv_len)
+    b = kv_len.numel()
+    hq, hkv = ws.n_q_heads, ws.n_kv_heads
+    q2 = q.view(b, hq * 128)
+    _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_decode: q layout")
+    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+          tuple(k_cache.shape[-2:]) == (hkv, 128) and v_cache.shape == k_cache.shape, "paged_decode: cache layout")
+    _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode: kv_indices must be int32")
+    _need(kv_start.dtype == torch.int64 and kv_start.numel() == b and kv_start.is_contiguous(), "paged_decode: kv_start")
+    _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and b <= ws.max_batch, "paged_decode: kv_len")
+    if out is None:
+        out = torch.empty((b, hq * 128), dtype=BF16, device=q.device)
+    else:
+        _need(out.is_contiguous() and out.numel() == b * hq * 128 and out.dtype == BF16, "paged_decode: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_paged_decode(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
+                                    _ptr(kv_start), _ptr(kv_len), _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv,
+                                    float(sm_scale), _stream()), "nvx_paged_decode")
+    return out
+
+
+def prefill_plan_ws(batch: int, device):
+    lib = _lib.load()
+    return torch.zeros(lib.nvx_prefill_plan_ws_ints(batch), dtype=torch.int32, device=device)
+
+
+def prefill_plan(qo_indptr, plan_ws):
+    _dev(qo_indptr, plan_ws)
+    b = qo_indptr.numel() - 1
+    _need(qo_indptr.dtype == torch.int32 and qo_indptr.is_contiguous() and b > 0, "prefill_plan: qo_indptr")
+    lib = _lib.load()
+    _lib.check(lib.nvx_prefill_plan(_ptr(qo_indptr), b, _ptr(plan_ws), plan_ws.numel(), _stream()), "nvx_prefill_plan")
+
+
+def paged_prefill(q, k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, plan_ws, n_q_heads, n_kv_heads, sm_scale, out=None):
+    """q (T, Hq*128); causal varlen attention over paged K/V (attention.py:360-364)."""
+    _dev(q, k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, plan_ws)
+    t = q.shape[0]
+    b = qo_indptr.numel() - 1
+    q2 = q.view(t, n_q_heads * 128)
+    _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_prefill: q layout")
+    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+          tuple(k_cache.shape[-2:]) == (n_kv_heads, 128) and v_cache.shape == k_cache.shape, "paged_prefill: cache layout")
+    for name, x in (("qo_indptr", qo_indptr), ("kv_indptr", kv_indptr), ("kv_indices", kv_indices)):
+        _need(x.dtype == torch.int32 and x.is_contiguous(), f"paged_prefill: {name} must be contiguous int32")
+    _need(kv_indptr.numel() == b + 1, "paged_prefill: indptr lengths differ")
+    if out is None:
+        out = torch.empty((t, n_q_heads * 128), dtype=BF16, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_paged_prefill(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(qo_indptr),
+                                     _ptr(kv_indptr), _ptr(kv_indices), _ptr(plan_ws), _ptr(out), t, b, n_q_heads, n_kv_heads,
+                                     float(sm_scale), _stream()), "nvx_paged_prefill")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def _sampler_args(logits, temperatures, top_ks, top_ps, min_ps):
+    _dev(logits, temperatures, top_ks, top_ps, min_ps)
+    _need(logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (BF16, torch.float32), "sampler: logits layout")
+    b, v = logits.shape
+    _need(temperatures.dtype == torch.float32 and top_ps.dtype == torch.float32 and min_ps.dtype == torch.float32 and
+          top_ks.dtype == torch.int64, "sampler: parameter dtypes (float32, int64)")
+    for x in (temperatures, top_ks, top_ps, min_ps):
+        _need(x.numel() == b and x.is_contiguous(), "sampler: one parameter per row")
+    return b, v
+
+
+def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int, offset: int, out=None):
+    """Sampler.forward (sampler.py:39-55): one token id per row, Philox(seed, offset) Gumbel-max draw."""
+    b, v = _sampler_args(logits, temperatures, top_ks, top_ps, min_ps)
+    if out is None:
+        out = torch.empty((b,), dtype=torch.int64, device=logits.device)
+    else:
+        _need(out.dtype == torch.int64 and out.numel() >= b and out.is_contiguous(), "sample: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_sample(_ptr(logits), int(logits.dtype == torch.float32), logits.stride(0), _ptr(temperatures),
+                              _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), b, v, seed & (2**64 - 1), offset & (2**64 - 1),
+                              _ptr(out), _stream()), "nvx_sample")
+    return out
+
+
+def sampler_probs(logits, temperatures, top_ks, top_ps, min_ps):
+    """The distribution the sampler draws from (after temperature, top-k, top-p, min-p), fp32 (B, V)."""
+    b, v = _sampler_args(logits, temperatures, top_ks, top_ps, min_ps)
+    probs = torch.empty((b, v), dtype=torch.float32, device=logits.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_sampler_probs(_ptr(logits), int(logits.dtype == torch.float32), logits.stride(0), _ptr(temperatures),
+                                     _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), b, v, _ptr(probs), _stream()),
+               "nvx_sampler_probs")
+    return probs
+
+
+# ---------------------------------------------------------------------------------------------
+def block_table_write_rows(kv_indices, kv_indptr, rows, table):
+    _dev(kv_indices, kv_indptr, rows, table)
+    b = rows.numel()
+    _need(table.dim() == 2 and table.is_contiguous() and table.dtype == torch.int32, "block_table_write_rows: table")
+    for x in (kv_indices, kv_indptr, rows):
+        _need(x.dtype == torch.int32 and x.is_contiguous(), "block_table_write_rows: int32 inputs")
+    _need(kv_indptr.numel() == b + 1, "block_table_write_rows: indptr length")
+    lib = _lib.load()
+    _lib.check(lib.nvx_block_table_write_rows(_ptr(kv_indices), _ptr(kv_indptr), _ptr(rows), b, _ptr(table), table.shape[0],
+                                              table.shape[1], _stream()), "nvx_block_table_write_rows")
+
+
+def decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids):
+    _dev(step, table, kv_start, kv_len, out_slots, positions, input_ids)
+    _need(step.dtype == torch.int32 and step.numel() >= 4 + 4 * stride and step.is_contiguous(), "decode_step_setup: step buffer")
+    _need(table.dim() == 2 and table.is_contiguous() and table.dtype == torch.int32, "decode_step_setup: table")
+    _need(kv_len.dtype == torch.int32 and all(x.dtype == torch.int64 for x in (kv_start, out_slots, positions, input_ids)),
+          "decode_step_setup: output dtypes")
+    for x in (kv_start, kv_len, out_slots, positions, input_ids):
+        _need(x.numel() >= padded_batch and x.is_contiguous(), "decode_step_setup: output sizes")
+    lib = _lib.load()
+    _lib.check(lib.nvx_decode_step_setup(_ptr(step), stride, padded_batch, _ptr(table), table.shape[0], table.shape[1], pad_start,
+                                         _ptr(kv_start), _ptr(kv_len), _ptr(out_slots), _ptr(positions), _ptr(input_ids),
+                                         _stream()), "nvx_decode_step_setup")

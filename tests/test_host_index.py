@@ -1,0 +1,82 @@
+"""Product host logic (allocator, radix tree, KV manager, scheduler, engine core) vs the reference's golden traces."""
+import pytest
+
+from helpers import bench_workload, golden_json
+from trace_drivers import (ProductEngineAdapter, ProductRadixAdapter, dump_node_tree, replay_bench_trace,
+                           replay_radix_program, replay_small_trace)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_radix_program(i):
+    replay_radix_program(ProductRadixAdapter, golden_json("g1_radix.json")["traces"][i])
+
+
+def test_corner_cases():
+    from nano_vllm_x_amd.core.kv_cache import KVCacheAllocator, RadixTree
+
+    c = golden_json("g1_radix.json")["corner"]
+    a = KVCacheAllocator(8)
+    assert [a.alloc(3), a.alloc(2)] == c["alloc_order"]
+    a.free([1, 0])
+    assert [a.alloc(2), a.alloc(4), a.alloc(1)] == c["after_free"]
+    t = RadixTree(KVCacheAllocator(8))
+    with pytest.raises(IndexError):
+        t.match_prefix([])
+    with pytest.raises(IndexError):
+        t.insert([], [])
+    t.insert([5, 6, 7], [0, 1])
+    t.insert([5, 6, 8, 9], [])
+    assert dump_node_tree(t.root) == c["ragged_tree"]
+    assert [t.match_prefix([5, 6, 8])[0], t.match_prefix([5, 6, 7, 1])[0]] == c["ragged_match"]
+    assert dump_node_tree(t.root) == c["ragged_tree_after_match"]
+
+
+def test_scheduler_bench_trace():
+    g = golden_json("g2_sched_bench.json")
+    prompts, max_tokens = bench_workload()
+    replay_bench_trace(ProductEngineAdapter, g, prompts, max_tokens)
+
+
+def test_scheduler_small_trace():
+    replay_small_trace(ProductEngineAdapter, golden_json("g2_sched_small.json"))
+
+
+def test_kv_exhaustion_preempts_instead_of_spinning():
+    """Where the reference loops forever, the victim is preempted and re-prefilled later."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams, SequenceStatus
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    e = EngineCore(kv_cache_size=20, max_bs=4, context_len=64)
+    for name in ("a", "b"):
+        e.add_sequence(name, list(range(9)), SamplingParams(ignore_eos=True, max_new_tokens=6))
+    b = e.scheduler.schedule()
+    assert b.forward_mode == ForwardMode.PREFILL and b.num_seqs == 2
+    e.update_from_output(b, [1, 1])
+    b = e.scheduler.schedule()           # 18 used, both need one more: fits exactly
+    assert b.forward_mode == ForwardMode.DECODE and b.num_seqs == 2
+    e.update_from_output(b, [1, 1])
+    b = e.scheduler.schedule()           # pool exhausted: "b" is preempted to make room for "a"
+    assert [s.seq_id for s in b.seqs] == ["a"]
+    sb = e.scheduler.get_sequence("b")
+    assert sb.status == SequenceStatus.WAITING and sb.kv_indices == [] and e.scheduler.waiting[0] is sb
+    e.update_from_output(b, [1])
+    steps = 0
+    while e.has_unfinished_sequences() and steps < 100:
+        b = e.scheduler.schedule()
+        if b is None:
+            break
+        e.update_from_output(b, [1] * b.num_seqs)
+        steps += 1
+    assert not e.has_unfinished_sequences()
+
+
+def test_single_sequence_too_large_returns_none():
+    from nano_vllm_x_amd.core.common import SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    e = EngineCore(kv_cache_size=8, max_bs=4, context_len=64)
+    e.add_sequence("a", [1, 2, 3, 4, 5, 6, 7, 8], SamplingParams(ignore_eos=True, max_new_tokens=4))
+    b = e.scheduler.schedule()
+    e.update_from_output(b, [9])
+    assert e.scheduler.schedule() is None     # no slot, nobody to preempt: the step yields nothing
+    assert [s.seq_id for s in e.scheduler.running] == ["a"]
