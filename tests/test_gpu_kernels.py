@@ -1,0 +1,382 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the oracle and the golden vectors.
+
+Tolerances (stated per test):
+  * integer/byte work (KV scatter, block-table kernels): bit-exact;
+  * RoPE: bit-exact against the reference's eager output (every rounding is reproduced);
+  * RMSNorm, SiluAndMul, fused qk-norm+RoPE: <= 1 bf16 ulp (fp32 reduction order / expf differ);
+  * decode attention (fp32 probabilities): |out - fp32 oracle| <= 1e-3 * max(1, |oracle|) + the rounding of
+    the bf16 output (half an ulp = 2^-9 relative) -- the fp32-accumulated value is what is held to 1e-3;
+  * prefill attention: the probabilities enter the PV MFMA as bf16 (as in every tensor-core flash
+    kernel, the reference's backend included), which adds at most 2^-9 * max|V| to the bound above;
+  * sampler probabilities: rtol 2e-5 on kept tokens, masks identical.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import bf16_ulp_diff, from_bits, golden_json, golden_npz, to_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nano_vllm_x_amd import _lib, ops as _ops
+
+    _lib.load()
+    return _ops
+
+
+def attn_close(got: torch.Tensor, want_f32: torch.Tensor, p_bf16_vmax: float = 0.0):
+    got = got.float().cpu()
+    want = want_f32.float().cpu()
+    tol = 1e-3 * torch.clamp(want.abs(), min=1.0) + want.abs() * 2.0 ** -8 + p_bf16_vmax * 2.0 ** -9 + 1e-6
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outside tolerance; max err {(got - want).abs().max():.3e}"
+
+
+# -----------------------------------------------------------------------------------------------
+def test_store_kv_golden(ops):
+    g = golden_npz("g4_store_kv.npz")
+    hq, hkv, d, t, slots, layers, start_layer, layer = g["meta"].tolist()
+    qkv = from_bits(g["qkv"]).to(DEV)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    kc, vc = from_bits(g["k_before"]).to(DEV), from_bits(g["v_before"]).to(DEV)
+    li = layer - start_layer
+    ops.store_kvcache(k.view(-1, hkv, d), v.view(-1, hkv, d), kc[li], vc[li], torch.from_numpy(g["idx"]).to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(to_bits(kc), g["k_after"]) and np.array_equal(to_bits(vc), g["v_after"])
+
+
+def test_store_kv_large_and_skip(ops):
+    from oracle.layers_oracle import store_kv_oracle
+
+    gen = torch.Generator().manual_seed(1)
+    t, hkv, d, slots = 3000, 8, 128, 5000
+    qkv = torch.randn(t, (16 + 2 * hkv) * d, generator=gen).to(torch.bfloat16)
+    perm = torch.randperm(slots, generator=gen)[:t]
+    perm[::7] = -1
+    k = qkv[:, 16 * d:(16 + hkv) * d]
+    v = qkv[:, (16 + hkv) * d:]
+    kc0 = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
+    vc0 = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
+    kc_ref, vc_ref = to_bits(kc0).copy(), to_bits(vc0).copy()
+    store_kv_oracle(to_bits(k.contiguous()).reshape(t, hkv, d), to_bits(v.contiguous()).reshape(t, hkv, d), kc_ref, vc_ref, perm.numpy())
+    qd = qkv.to(DEV)
+    kd, vd = kc0.to(DEV), vc0.to(DEV)
+    ops.store_kvcache(qd[:, 16 * d:(16 + hkv) * d].view(t, hkv, d), qd[:, (16 + hkv) * d:].view(t, hkv, d), kd, vd, perm.to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(to_bits(kd), kc_ref) and np.array_equal(to_bits(vd), vc_ref)
+    # empty input is a no-op
+    ops.store_kvcache(qd[:0, :hkv * d].view(0, hkv, d), qd[:0, :hkv * d].view(0, hkv, d), kd, vd, perm[:0].to(DEV))
+
+
+def test_rmsnorm_golden(ops):
+    g = golden_npz("g5_layers.npz")
+    for tag in ("h1024", "h4096", "hd128"):
+        w, x, r = (from_bits(g[f"rms_{tag}_{n}"]).to(DEV) for n in ("w", "x", "res"))
+        y = ops.rmsnorm(x, w, 1e-6)
+        y2, r2 = ops.rmsnorm(x, w, 1e-6, r)
+        torch.cuda.synchronize()
+        assert bf16_ulp_diff(y, from_bits(g[f"rms_{tag}_y"])) <= 1
+        assert bf16_ulp_diff(y2, from_bits(g[f"rms_{tag}_y_res"])) <= 1
+        assert np.array_equal(to_bits(r2), g[f"rms_{tag}_res_out"])  # one fp32 add, one rounding: exact
+        frac = (to_bits(y) == g[f"rms_{tag}_y"]).mean()
+        assert frac > 0.98, frac
+
+
+@pytest.mark.parametrize("hidden", [128, 1024, 2560, 5120, 8192])
+def test_rmsnorm_vs_oracle_sizes(ops, hidden):
+    from oracle.layers_oracle import rmsnorm_oracle
+
+    gen = torch.Generator().manual_seed(hidden)
+    x = (torch.randn(37, hidden, generator=gen) * 2).to(torch.bfloat16)
+    r = torch.randn(37, hidden, generator=gen).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(hidden, generator=gen)).to(torch.bfloat16)
+    y_ref, r_ref = rmsnorm_oracle(x, w, 1e-6, r)
+    y, ro = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6, r.to(DEV))
+    assert bf16_ulp_diff(y, y_ref) <= 1 and np.array_equal(to_bits(ro), to_bits(r_ref))
+    # fp32 weight and a row-strided input view
+    big = torch.zeros(37, hidden + 64, dtype=torch.bfloat16)
+    big[:, :hidden] = x
+    y3 = ops.rmsnorm(big.to(DEV)[:, :hidden], w.float().to(DEV), 1e-6)
+    assert bf16_ulp_diff(y3, rmsnorm_oracle(x, w.float(), 1e-6)) <= 1
+
+
+def test_rope_golden_bit_exact(ops):
+    from oracle.layers_oracle import rope_table_oracle
+
+    g = golden_npz("g5_layers.npz")
+    table = rope_table_oracle(128, 40960, 1000000).to(DEV)
+    pos = torch.from_numpy(g["rope_pos"]).to(DEV)
+    q, k = from_bits(g["rope_q"]).to(DEV), from_bits(g["rope_k"]).to(DEV)
+    qo, ko = ops.rope(pos, q, k, table)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_bits(qo), g["rope_q_out"]) and np.array_equal(to_bits(ko), g["rope_k_out"])
+
+
+def test_silu_mul_golden(ops):
+    g = golden_npz("g5_layers.npz")
+    y = ops.silu_mul(from_bits(g["silu_x"]).to(DEV))
+    assert bf16_ulp_diff(y, from_bits(g["silu_y"])) <= 1
+    assert (to_bits(y) == g["silu_y"]).mean() > 0.98
+
+
+def test_fused_qknorm_rope_store_vs_unfused_oracle(ops):
+    from oracle.layers_oracle import rmsnorm_oracle, rope_rows_oracle, rope_table_oracle
+
+    gen = torch.Generator().manual_seed(3)
+    t, hq, hkv, d, slots = 19, 16, 8, 128, 64
+    qkv = (torch.randn(t, (hq + 2 * hkv) * d, generator=gen) * 1.5).to(torch.bfloat16)
+    qw = (1 + 0.2 * torch.randn(d, generator=gen)).to(torch.bfloat16)
+    kw = (1 + 0.2 * torch.randn(d, generator=gen)).to(torch.bfloat16)
+    pos = torch.randint(0, 4096, (t,), generator=gen)
+    slot = torch.randperm(slots, generator=gen)[:t]
+    slot[3] = -1
+    table = rope_table_oracle(128, 4096, 1000000)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    qn = rmsnorm_oracle(q.reshape(t, hq, d), qw, 1e-6).reshape(t, hq * d)
+    kn = rmsnorm_oracle(k.reshape(t, hkv, d), kw, 1e-6).reshape(t, hkv * d)
+    q_ref = rope_rows_oracle(qn, table[pos], d)
+    k_ref = rope_rows_oracle(kn, table[pos], d)
+    kc = torch.zeros(slots, hkv, d, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros(slots, hkv, d, dtype=torch.bfloat16, device=DEV)
+    q_out = ops.qknorm_rope_store(qkv.to(DEV), pos.to(DEV), table.to(DEV), qw.to(DEV), kw.to(DEV), 1e-6, slot.to(DEV), kc, vc, hq, hkv)
+    torch.cuda.synchronize()
+    # a 1-ulp difference after the norm can grow through the rotation's three roundings
+    assert bf16_ulp_diff(q_out, q_ref) <= 2
+    live = slot >= 0
+    assert bf16_ulp_diff(kc.cpu()[slot[live]].reshape(-1, hkv * d), k_ref[live]) <= 2
+    assert np.array_equal(to_bits(vc.cpu()[slot[live]].reshape(-1, hkv * d)), to_bits(v[live].contiguous()))
+    untouched = torch.ones(slots, dtype=torch.bool)
+    untouched[slot[live]] = False
+    assert not kc.cpu()[untouched].any() and not vc.cpu()[untouched].any()
+    assert (to_bits(q_out) == to_bits(q_ref)).mean() > 0.97
+
+
+# -----------------------------------------------------------------------------------------------
+def _random_cache(gen, slots, hkv, d=128):
+    kc = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
+    vc = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
+    return kc, vc
+
+
+def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
+    from oracle.attention_oracle import paged_attention_oracle
+
+    gen = torch.Generator().manual_seed(seed)
+    b = len(lens)
+    total = sum(lens)
+    slots = slots or max(64, 2 * total)
+    kc, vc = _random_cache(gen, slots, hkv)
+    perm = torch.randperm(slots, generator=gen)[:total].to(torch.int32)
+    q = torch.randn(b, hq, 128, generator=gen).to(torch.bfloat16)
+    indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    ref = paged_attention_oracle(q.float(), kc, vc, np.arange(b + 1), indptr, perm.numpy(), 128 ** -0.5)
+    ws = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    if strided_table:   # rows of a 2-D table instead of a packed CSR list
+        cap = max(lens) + 5
+        table = torch.full((b, cap), -7, dtype=torch.int32)
+        for i in range(b):
+            table[i, :lens[i]] = perm[indptr[i]:indptr[i + 1]]
+        kv_indices = table.flatten().to(DEV)
+        kv_start = (torch.arange(b, dtype=torch.int64) * cap).to(DEV)
+    else:
+        kv_indices = perm.to(DEV)
+        kv_start = torch.from_numpy(indptr[:-1].astype(np.int64)).to(DEV)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    ops.decode_plan(kv_len, ws)
+    out = ops.paged_decode(q.to(DEV).view(b, hq * 128), kc.to(DEV), vc.to(DEV), kv_indices, kv_start, kv_len, ws, 128 ** -0.5)
+    torch.cuda.synchronize()
+    attn_close(out.view(b, hq, 128), ref)
+    return ws
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2)])
+def test_decode_attention_small(ops, hq, hkv):
+    _decode_case(ops, 10 + hq, [1, 2, 31, 32, 33, 127, 128, 129, 300], hq, hkv)
+
+
+def test_decode_attention_split_sequences(ops):
+    # one long sequence alone: the plan must cut it into many chunks and the merge kernel must run
+    ws = _decode_case(ops, 21, [4000], 16, 8)
+    assert int(ws.plan[0]) > 1
+    _decode_case(ops, 22, [3000, 5, 700, 1], 16, 8, strided_table=True)
+
+
+def test_decode_attention_bench_like_batch(ops):
+    rng = np.random.default_rng(5)
+    lens = rng.integers(107, 1100, size=123).tolist()
+    _decode_case(ops, 23, lens, 16, 8)
+
+
+def test_decode_zero_length_row_gives_zeros(ops):
+    gen = torch.Generator().manual_seed(2)
+    kc, vc = _random_cache(gen, 64, 8)
+    q = torch.randn(2, 16 * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    ws = ops.DecodeWorkspace(2, 16, 8, DEV)
+    kv_len = torch.tensor([0, 3], dtype=torch.int32, device=DEV)
+    ops.decode_plan(kv_len, ws)
+    out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.arange(8, dtype=torch.int32, device=DEV),
+                           torch.tensor([0, 2], dtype=torch.int64, device=DEV), kv_len, ws, 0.1)
+    assert not out[0].any() and out[1].any()
+
+
+# -----------------------------------------------------------------------------------------------
+def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
+    from oracle.attention_oracle import paged_attention_oracle
+
+    gen = torch.Generator().manual_seed(seed)
+    b = len(q_lens)
+    t, total = sum(q_lens), sum(kv_lens)
+    slots = max(64, 2 * total)
+    kc, vc = _random_cache(gen, slots, hkv)
+    perm = torch.randperm(slots, generator=gen)[:total].to(torch.int32)
+    q = torch.randn(t, hq, 128, generator=gen).to(torch.bfloat16)
+    qo = np.concatenate(([0], np.cumsum(q_lens))).astype(np.int32)
+    kp = np.concatenate(([0], np.cumsum(kv_lens))).astype(np.int32)
+    qo_d, kp_d = torch.from_numpy(qo).to(DEV), torch.from_numpy(kp).to(DEV)
+    plan = ops.prefill_plan_ws(b, DEV)
+    ops.prefill_plan(qo_d, plan)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    out = ops.paged_prefill(q.to(DEV).view(t, hq * 128), kcd, vcd, qo_d, kp_d, perm.to(DEV), plan, hq, hkv, 128 ** -0.5)
+    torch.cuda.synchronize()
+    if check_oracle:
+        ref = paged_attention_oracle(q.float(), kc, vc, qo, kp, perm.numpy(), 128 ** -0.5)
+        attn_close(out.view(t, hq, 128), ref, p_bf16_vmax=float(vc.float().abs().max()))
+    # independent on-device check: every query row as its own decode row over its visible keys
+    row_start, row_len = [], []
+    for i in range(b):
+        off = kv_lens[i] - q_lens[i]
+        for j in range(q_lens[i]):
+            row_start.append(int(kp[i]))
+            row_len.append(j + off + 1)
+    ws = ops.DecodeWorkspace(t, hq, hkv, DEV)
+    kv_len = torch.tensor(row_len, dtype=torch.int32, device=DEV)
+    ops.decode_plan(kv_len, ws)
+    out2 = ops.paged_decode(q.to(DEV).view(t, hq * 128), kcd, vcd, perm.to(DEV),
+                            torch.tensor(row_start, dtype=torch.int64, device=DEV), kv_len, ws, 128 ** -0.5)
+    torch.cuda.synchronize()
+    # two bf16 outputs of the same fp32 quantity: 1e-3 + one rounding each + the bf16 probabilities of the MFMA path
+    d = (out.float() - out2.float()).abs()
+    tol = 2e-3 * torch.clamp(out2.float().abs(), min=1.0) + out2.float().abs() * 2.0 ** -7 + float(vc.float().abs().max()) * 2.0 ** -9
+    assert not (d > tol).any(), f"prefill vs per-row decode: max diff {d.max():.3e}"
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2)])
+def test_prefill_attention_small(ops, hq, hkv):
+    q_lens = [1, 5, 31, 32, 33, 64, 65, 130, 200]
+    _prefill_case(ops, 30 + hq, q_lens, q_lens, hq, hkv)
+
+
+def test_prefill_attention_with_cached_prefix(ops):
+    # queries are the LAST q_len positions of kv_len keys (attention.py:67-81 with cached_kv_len > 0)
+    _prefill_case(ops, 41, [3, 40, 1, 100], [50, 40, 300, 164], 16, 8)
+
+
+def test_prefill_attention_bench_like(ops):
+    rng = np.random.default_rng(7)
+    lens = rng.integers(100, 1025, size=24).tolist()
+    _prefill_case(ops, 42, lens, lens, 16, 8, check_oracle=False)
+
+
+def test_prefill_matches_oracle_long_rows(ops):
+    _prefill_case(ops, 43, [1024, 517], [1024, 517], 16, 8)
+
+
+# -----------------------------------------------------------------------------------------------
+def test_sampler_probs_golden(ops):
+    g = golden_npz("g6_sampler.npz")
+    logits = from_bits(g["logits"]).to(DEV)
+    args = [torch.from_numpy(g[n]).to(DEV) for n in ("temps", "top_k", "top_p", "min_p")]
+    probs = ops.sampler_probs(logits, args[0], args[1], args[2], args[3]).cpu().numpy()
+    assert np.array_equal(probs > 0, g["keep_after_minp"])
+    np.testing.assert_allclose(probs, g["probs"], rtol=2e-5, atol=1e-9)
+    # fp32 logits input path
+    probs32 = ops.sampler_probs(logits.float(), args[0], args[1], args[2], args[3]).cpu().numpy()
+    np.testing.assert_allclose(probs32, g["probs"], rtol=2e-5, atol=1e-9)
+
+
+def test_sampler_probs_full_vocab_vs_oracle(ops):
+    from oracle.layers_oracle import sampler_masks_oracle
+
+    gen = torch.Generator().manual_seed(9)
+    v = 151936
+    logits = (torch.randn(5, v, generator=gen) * 3).to(torch.bfloat16)
+    temps = np.array([0.6, 1.0, 0.9, 0.7, 1.2], dtype=np.float32)
+    top_k = np.array([v, 40, v, 1000, 3], dtype=np.int64)
+    top_p = np.array([1.0, 1.0, 0.8, 0.95, 1.0], dtype=np.float32)
+    min_p = np.array([0.0, 0.0, 0.0, 0.02, 0.0], dtype=np.float32)
+    _, keep, probs_ref = sampler_masks_oracle(logits.float().numpy(), temps, top_k, top_p, min_p)
+    probs = ops.sampler_probs(logits.to(DEV), *(torch.from_numpy(a).to(DEV) for a in (temps, top_k, top_p, min_p))).cpu().numpy()
+    got_keep = probs > 0
+    # the top-p cut compares a 150k-term fp32 running sum with 1 - p: tokens within 1e-4 of the cut may differ
+    diff = got_keep != keep
+    assert diff.sum(axis=1).max() <= 64, diff.sum(axis=1)
+    same = ~diff.any(axis=1)
+    assert same[[0, 1, 4]].all()     # rows without top-p must match exactly
+    np.testing.assert_allclose(probs[same], probs_ref[same], rtol=5e-5, atol=1e-9)
+
+
+def test_sampler_draws_follow_the_distribution(ops):
+    gen = torch.Generator().manual_seed(11)
+    v, n = 64, 20000
+    row = (torch.randn(v, generator=gen) * 1.5).to(torch.bfloat16)
+    logits = row.repeat(n, 1).to(DEV)
+    ones = torch.ones(n, device=DEV)
+    t = ones * 0.8
+    ids = ops.sample(logits, t, torch.full((n,), v, dtype=torch.int64, device=DEV), ones, ones * 0, seed=123, offset=7)
+    ids2 = ops.sample(logits, t, torch.full((n,), v, dtype=torch.int64, device=DEV), ones, ones * 0, seed=123, offset=7)
+    assert torch.equal(ids, ids2)                      # reproducible for a given (seed, offset)
+    ids3 = ops.sample(logits, t, torch.full((n,), v, dtype=torch.int64, device=DEV), ones, ones * 0, seed=123, offset=8)
+    assert not torch.equal(ids, ids3)
+    p = torch.softmax(row.float() / 0.8, dim=-1).numpy()
+    counts = np.bincount(ids.cpu().numpy(), minlength=v).astype(np.float64)
+    chi2 = ((counts - n * p) ** 2 / (n * p)).sum()
+    assert chi2 < 130, chi2          # 63 degrees of freedom: P(chi2 > 130) < 1e-6
+    # filtered rows: draws stay inside the kept set, top_k = 1 is the argmax
+    ids_k = ops.sample(logits[:4000], t[:4000], torch.full((4000,), 5, dtype=torch.int64, device=DEV), ones[:4000], ones[:4000] * 0, 1, 0)
+    top5 = set(torch.topk(row.float(), 5).indices.tolist())
+    assert set(ids_k.cpu().tolist()) <= top5 and len(set(ids_k.cpu().tolist())) > 1
+    ids_1 = ops.sample(logits[:16], t[:16], torch.ones(16, dtype=torch.int64, device=DEV), ones[:16], ones[:16] * 0, 1, 0)
+    assert (ids_1 == int(torch.argmax(row.float()))).all()
+
+
+# -----------------------------------------------------------------------------------------------
+def test_block_table_kernels(ops):
+    rows, cap, max_bs = 6, 16, 8
+    table = torch.full((rows, cap), -1, dtype=torch.int32, device=DEV)
+    kv = torch.tensor([10, 11, 12, 20, 21, 30], dtype=torch.int32, device=DEV)
+    indptr = torch.tensor([0, 3, 5, 6], dtype=torch.int32, device=DEV)
+    ops.block_table_write_rows(kv, indptr, torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV), table)
+    want = torch.full((rows, cap), -1, dtype=torch.int32)
+    want[4, :3] = torch.tensor([10, 11, 12]); want[0, :2] = torch.tensor([20, 21]); want[2, :1] = 30
+    assert torch.equal(table.cpu(), want)
+    step = torch.zeros(4 + 4 * max_bs, dtype=torch.int32)
+    step[0] = 3
+    step[4:7] = torch.tensor([4, 0, 2])                       # row
+    step[4 + max_bs:7 + max_bs] = torch.tensor([3, 2, 1])     # pos
+    step[4 + 2 * max_bs:7 + 2 * max_bs] = torch.tensor([13, 22, 31])  # slot
+    step[4 + 3 * max_bs:7 + 3 * max_bs] = torch.tensor([7, 8, 9])     # token
+    kv_start = torch.zeros(max_bs, dtype=torch.int64, device=DEV)
+    kv_len = torch.zeros(max_bs, dtype=torch.int32, device=DEV)
+    out_slots, positions, input_ids = (torch.zeros(max_bs, dtype=torch.int64, device=DEV) for _ in range(3))
+    pad_start = 5 * cap
+    ops.decode_step_setup(step.to(DEV), max_bs, 4, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids)
+    want[4, 3] = 13; want[0, 2] = 22; want[2, 1] = 31
+    assert torch.equal(table.cpu(), want)
+    assert kv_start[:4].tolist() == [4 * cap, 0, 2 * cap, pad_start]
+    assert kv_len[:4].tolist() == [4, 3, 2, 1]
+    assert out_slots[:4].tolist() == [13, 22, 31, -1]          # padded row: scatter skipped (attention.py:263-265)
+    assert positions[:4].tolist() == [3, 2, 1, 0] and input_ids[:4].tolist() == [7, 8, 9, 0]
+
+
+def test_bad_arguments_raise(ops):
+    x = torch.zeros(4, 100, dtype=torch.bfloat16, device=DEV)   # hidden not a multiple of 8
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(x, torch.ones(100, dtype=torch.bfloat16, device=DEV), 1e-6)
+    with pytest.raises(RuntimeError):
+        ops.silu_mul(torch.zeros(4, 10, dtype=torch.bfloat16))   # CPU tensor: no fallback
