@@ -90,6 +90,13 @@ class Engine(EngineCore):
         output_ids = self.model_runner.execute_model(batch)
         return self.update_from_output(batch, output_ids)
 
+    def reset(self):
+        """Forget every sequence and every cached prefix (fresh scheduler, same pool and graphs)."""
+        for seq_id in list(self.model_runner.block_table.row_of):
+            self.model_runner.block_table.release(seq_id)
+        self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs)
+        self.scheduler.on_release = self.model_runner.release_sequence
+
     def wait_until_ready(self):
         return True
 

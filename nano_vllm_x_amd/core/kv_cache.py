@@ -57,25 +57,44 @@ class KVCachePool:
 
 class KVCacheAllocator:
     """Stack of free token slots (kv_cache.py:101-117): a fresh pool hands out 0, 1, 2, ...; freed
-    slots are reissued last-in first-out."""
+    slots are reissued last-in first-out.
+
+    The reference materialises the whole stack as a Python list of `size` integers; 288 GB of HBM
+    hold millions of slots per rank, so here the never-yet-used tail of the stack is kept as a
+    counter (`_fresh`: slots _fresh .. size-1 are untouched and lie BELOW every freed slot) and only
+    freed slots are stored.  Pops come out in exactly the same order."""
 
     def __init__(self, size: int):
         self.size = size
-        self.free_slots = list(range(size - 1, -1, -1))
+        self._fresh = 0          # next never-used slot
+        self._returned: list = []   # freed slots, top of the stack at the end
+
+    @property
+    def free_slots(self) -> list:
+        """The stack as the reference stores it (bottom first).  O(size): for inspection and tests."""
+        return list(range(self.size - 1, self._fresh - 1, -1)) + self._returned
+
+    def num_free(self) -> int:
+        return (self.size - self._fresh) + len(self._returned)
 
     def alloc(self, need_size: int):
-        pool = self.free_slots
-        if need_size > len(pool):
+        if need_size > self.num_free():
             return None
-        if need_size == 0:
-            return []
-        taken = pool[-need_size:]
-        del pool[-need_size:]
-        taken.reverse()
-        return taken
+        got = []
+        ret = self._returned
+        take = min(need_size, len(ret))
+        if take:
+            got = ret[-take:]
+            del ret[-take:]
+            got.reverse()
+        rest = need_size - take
+        if rest:
+            got.extend(range(self._fresh, self._fresh + rest))
+            self._fresh += rest
+        return got
 
     def free(self, free_index: abc.Iterable):
-        self.free_slots.extend(free_index)
+        self._returned.extend(free_index)
 
 
 class _Clock:

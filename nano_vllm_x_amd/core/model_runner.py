@@ -1,0 +1,260 @@
+"""Per-rank model runner: weights, KV pool, per-step input preparation, eager and graph execution.
+
+Interface of nanovllmx/core/model_runner.py (`load_model` :79-131, `initialize_kv_cache` :133-157,
+`profile_kv_cache_size` :159-173, `prepare_input` :175-189, `prepare_sampling_params` :191-219,
+`prepare_last_hidden_states` :221-227, `execute_model` :229-274, `capture_graph` :332-417).
+
+What differs, by design, on MI355X:
+  * a decode step is ONE hipGraph launch that starts with the block-table update and the split plan
+    (both device side), so the host uploads 4 integers per sequence and nothing else;
+  * list -> tensor conversion is numpy on whole batches into one staging buffer;
+  * the sampled ids are broadcast from rank 0, so every rank's scheduler stays in lockstep without
+    any host-side message passing.
+"""
+from __future__ import annotations
+
+import gc
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import distributed as tpd
+from .. import ops
+from ..layers.attention import AttentionBackend, AttentionMetadata, BlockTable, PagedDecodeWrapper, attention_kv_cache
+from ..layers.sampler import Sampler
+from ..qwen3 import Qwen3Config, Qwen3ForCausalLM, load_config
+from .common import ForwardBatch, ForwardMode
+from .hip_graph import HIPGraph, decode_batch_ladder
+from .kv_cache import KVCachePool
+
+_DTYPES = {"half": torch.float16, "float16": torch.float16, "float": torch.float32, "float32": torch.float32,
+           "bfloat16": torch.bfloat16}
+
+
+def get_model_config_per_gpu(cfg: Qwen3Config, tp_size: int):
+    """Per-rank head counts (model_runner.py:43-44): query heads split, kv heads split or replicated."""
+    return cfg.num_attention_heads // tp_size, max(1, cfg.num_key_value_heads // tp_size), cfg.head_dim
+
+
+class ModelRunner:
+    def __init__(self, model: str, max_bs: int, tp_size: int = 1, nccl_port: int = 29500,
+                 device_ids: Optional[list] = None, enforce_eager: bool = False, context_len: int = 2048,
+                 seed: int = 0, config: Optional[Qwen3Config] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ModelRunner needs an MI355X: the HIP path has no CPU fallback")
+        self.model_path, self.max_bs, self.context_len = model, max_bs, context_len
+        self.enforce_eager, self.seed = enforce_eager, seed
+        self.rank = tpd.init_tensor_parallel(tp_size, port=nccl_port, device_ids=device_ids)
+        self.tp_size = tp_size
+        if tp_size == 1:
+            torch.cuda.set_device(device_ids[0] if device_ids else 0)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._config_override = config
+        self.graph: Optional[HIPGraph] = None
+        self.block_table: Optional[BlockTable] = None
+        self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0}
+
+    # -- set-up -----------------------------------------------------------------------------------
+    def load_model(self, state_dict_iter=None):
+        self.hf_config = self._config_override or load_config(self.model_path)
+        cfg = self.hf_config
+        self.dtype = _DTYPES[cfg.torch_dtype]
+        if self.dtype != torch.bfloat16:
+            raise NotImplementedError("the HIP kernels are built for bfloat16 checkpoints")
+        self.num_heads, self.num_kv_heads, self.head_dim = get_model_config_per_gpu(cfg, self.tp_size)
+        self.num_layers = cfg.num_hidden_layers
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(self.dtype)
+        try:
+            with torch.device(self.device):
+                self.model = Qwen3ForCausalLM(cfg)
+        finally:
+            torch.set_default_dtype(prev)
+        self.model.finalize()
+        self.model.eval()
+        if state_dict_iter is not None:
+            self.model.load_weights(state_dict_iter)
+        else:
+            files = _safetensors_files(self.model_path)
+            if files:
+                self.model.load_weights(_iter_safetensors(files))
+            else:
+                self.model.init_random(self.seed)
+        self.sampler = Sampler(seed=self.seed)
+
+    def profile_kv_cache_size(self, gpu_memory_utilization: float = 0.9) -> int:
+        per_token = self.num_layers * self.num_kv_heads * self.head_dim * 2 * self.dtype.itemsize
+        gc.collect()
+        torch.cuda.empty_cache()
+        free, _total = torch.cuda.mem_get_info(self.device)
+        n = int(free * gpu_memory_utilization) // per_token
+        return tpd.tp_all_gather_min_int(n, self.device)
+
+    def initialize_kv_cache(self, kv_cache_size: int):
+        self.kv_cache_size = kv_cache_size
+        self.kv_cache = KVCachePool(dtype=self.dtype, device=self.device, num_tokens=kv_cache_size,
+                                    num_layers=self.num_layers, num_heads=self.num_kv_heads, head_dim=self.head_dim,
+                                    start_layer=0, end_layer=self.num_layers)
+        self.attn_backend = AttentionBackend(kv_cache=self.kv_cache, num_qo_heads=self.num_heads,
+                                             num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, dtype=self.dtype,
+                                             device=self.device)
+        n_rows = max(1024, 4 * self.max_bs) + 1
+        self.block_table = BlockTable(self.max_bs, n_rows, 2 * self.context_len, self.device)
+        self.decode_ws = ops.DecodeWorkspace(self.max_bs, self.num_heads, self.num_kv_heads, self.device)
+        self._sample_out = torch.zeros(self.max_bs, dtype=torch.int64, device=self.device)
+        self._sample_host = torch.zeros(self.max_bs, dtype=torch.int64, pin_memory=True)
+        if not self.enforce_eager:
+            self.graph = HIPGraph()
+            self.capture_graph()
+
+    # -- per-step host preparation -------------------------------------------------------------------
+    def prepare_input(self, batch: ForwardBatch):
+        ids = [t for s in batch.seqs for t in s.token_ids[s.cached_kv_len:]]
+        pos = np.concatenate([np.arange(s.cached_kv_len, len(s.token_ids), dtype=np.int64) for s in batch.seqs])
+        ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(self.device, non_blocking=True)
+        return ids_t, torch.from_numpy(pos).to(self.device, non_blocking=True)
+
+    def prepare_sampling_params(self, batch: ForwardBatch):
+        """One (4, B) fp32 upload: temperature, min_p, top_p, top_k (-1 -> vocabulary size,
+        model_runner.py:202-206).  Returns the four per-row device tensors."""
+        v = self.hf_config.vocab_size
+        n = batch.num_seqs
+        host = np.empty((4, n), dtype=np.float32)
+        for i, s in enumerate(batch.seqs):
+            sp = s.sampling_params
+            host[0, i], host[1, i], host[2, i] = sp.temperature, sp.min_p, sp.top_p
+            host[3, i] = v if sp.top_k == -1 else min(sp.top_k, v)
+        dev = torch.from_numpy(host).to(self.device, non_blocking=True)
+        return dev[0], dev[1], dev[2], dev[3].to(torch.int64)
+
+    @staticmethod
+    def prepare_last_hidden_states(batch: ForwardBatch, hidden_states: torch.Tensor) -> torch.Tensor:
+        last = np.cumsum([len(s.token_ids) - s.cached_kv_len for s in batch.seqs]) - 1
+        if len(last) == hidden_states.shape[0]:
+            return hidden_states   # decode: every row is a last row
+        return hidden_states[torch.from_numpy(last).to(hidden_states.device)]
+
+    # -- execution -----------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def compute_logits(self, batch: ForwardBatch) -> torch.Tensor:
+        """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token."""
+        decode = batch.forward_mode == ForwardMode.DECODE
+        if decode and self.graph is not None and self.graph.is_captured and batch.num_seqs <= self.graph.max_bs \
+                and self.block_table.fits(batch.seqs):
+            hidden = self._execute_model_graph(batch)
+            self.stats["graph_steps"] += 1
+        else:
+            hidden = self._execute_model_eager(batch)
+            if decode:
+                self.stats["eager_decode_steps"] += 1
+        self.stats["decode_steps" if decode else "prefill_steps"] += 1
+        hidden = self.prepare_last_hidden_states(batch, hidden)
+        return self.model.compute_logits(hidden)
+
+    @torch.inference_mode()
+    def execute_model(self, batch: ForwardBatch) -> list:
+        if batch.num_seqs == 0:
+            return []
+        logits = self.compute_logits(batch)
+        temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
+        n = batch.num_seqs
+        ids = self.sampler(logits, temperatures, min_ps, top_ps, top_ks, out=self._sample_out[:n] if n <= self.max_bs else None)
+        tpd.tp_broadcast(ids, src=0)
+        if n <= self.max_bs:
+            self._sample_host[:n].copy_(ids, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return self._sample_host[:n].tolist()
+        return ids.tolist()
+
+    def _execute_model_eager(self, batch: ForwardBatch) -> torch.Tensor:
+        input_ids, positions = self.prepare_input(batch)
+        md = self.attn_backend.build_metadata(batch)
+        with attention_kv_cache(self.model, md):
+            hidden = self.model(input_ids, positions)
+        # keep the device block table in step with what the scheduler decided
+        t = self.attn_backend.last_table
+        if batch.forward_mode == ForwardMode.PREFILL:
+            if all(len(s.kv_indices) <= self.block_table.row_capacity for s in batch.seqs) \
+                    and len(self.block_table.free_rows) >= batch.num_seqs:
+                self.block_table.write_prefilled(batch.seqs, t["paged_kv_indices"], t["paged_kv_indptr"])
+        else:
+            for s in batch.seqs:   # a decode step that ran eagerly: its row (if any) is now stale
+                self.block_table.release(s.seq_id)
+        return hidden
+
+    def _execute_model_graph(self, batch: ForwardBatch) -> torch.Tensor:
+        bs = batch.num_seqs
+        padded = self.graph.match_bs(bs)
+        self.block_table.stage_decode_step(batch.seqs)
+        self.graph.replay(padded)
+        return self.graph.get_output_buffer("hidden_states")[:bs]
+
+    def _decode_forward(self, bs: int) -> torch.Tensor:
+        """The body of a captured decode step for a padded batch of `bs` rows."""
+        bt = self.block_table
+        ops.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
+                              bt.positions, bt.input_ids)
+        ops.decode_plan(bt.kv_len[:bs], self.decode_ws)
+        wrapper = self._graph_wrappers[bs]
+        md = AttentionMetadata(forward_mode=ForwardMode.DECODE, kv_cache=self.kv_cache, output_kv_indices=bt.out_slots[:bs],
+                               wrapper=wrapper)
+        with attention_kv_cache(self.model, md):
+            return self.model(bt.input_ids[:bs], bt.positions[:bs])
+
+    @torch.inference_mode()
+    def capture_graph(self):
+        """Capture one decode graph per ladder size, largest first so the pool is sized once
+        (model_runner.py:393).  Static inputs: the step buffer of the block table; static output:
+        `hidden_states` (max_bs, hidden)."""
+        assert self.graph is not None
+        bt = self.block_table
+        sizes = decode_batch_ladder(self.max_bs)
+        hidden_out = torch.zeros((self.max_bs, self.hf_config.hidden_size), dtype=self.dtype, device=self.device)
+        self.graph.set_input_buffer("step", bt.step_dev)
+        self.graph.set_input_buffer("input_ids", bt.input_ids)
+        self.graph.set_input_buffer("positions", bt.positions)
+        self.graph.set_output_buffer("hidden_states", hidden_out)
+        self._graph_wrappers = {}
+        bt.step_dev.zero_()   # batch = 0: every row is a padding row during warm-up and capture
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for bs in reversed(sizes):
+                w = PagedDecodeWrapper(None, "NHD", use_cuda_graph=True)
+                w.bind_table(bt.table.view(-1), bt.kv_start, bt.kv_len, bs, self.decode_ws)
+                self._graph_wrappers[bs] = w
+                self._decode_forward(bs)   # warm-up outside capture (library handles, allocator pool)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for bs in reversed(sizes):
+            with self.graph.capture(bs):
+                hidden_out[:bs] = self._decode_forward(bs)
+        torch.cuda.synchronize()
+
+    # -- bookkeeping ---------------------------------------------------------------------------------
+    def release_sequence(self, seq):
+        if self.block_table is not None:
+            self.block_table.release(seq.seq_id)
+
+    def shutdown(self):
+        if self.graph is not None:
+            self.graph.clear()
+        tpd.shutdown()
+
+
+def _safetensors_files(path: str):
+    import glob
+    import os
+
+    return sorted(glob.glob(os.path.join(path, "*.safetensors"))) if os.path.isdir(path) else []
+
+
+def _iter_safetensors(files):
+    """(name, tensor) pairs of a checkpoint directory (nanovllmx/model_loader.py:22-48)."""
+    from safetensors import safe_open
+
+    for f in files:
+        with safe_open(f, framework="pt", device="cpu") as sf:
+            for name in sf.keys():
+                yield name, sf.get_tensor(name)

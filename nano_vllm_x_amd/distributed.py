@@ -1,0 +1,99 @@
+"""Tensor-parallel process group: one process per GPU, RCCL over xGMI (gloo on CPU for tests).
+
+Covers what the hot path uses of nanovllmx/distributed/{parallel_state,communication_op}.py: the TP
+group, the in-place all-reduce behind row-parallel linears and the vocab-parallel embedding
+(communication_op.py:41-52,153-156), the last-dim all-gather behind the LM head (:9-39,158-162) and a
+broadcast of sampled ids.  The path shards by KV head, so attention itself needs no exchange.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP = None
+_TP_RANK = 0
+_TP_SIZE = 1
+
+
+def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | None = None, port: int = 29500,
+                         device_ids: list | None = None):
+    """Join (or create) the process group.  Under torchrun the RANK/WORLD_SIZE/MASTER_* variables are
+    used; a single process with tp_size 1 needs no group at all."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    if tp_size <= 1:
+        _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+        return 0
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        if rank is None:
+            rank = int(os.environ.get("RANK", "0"))
+        if "MASTER_ADDR" in os.environ and "WORLD_SIZE" in os.environ:
+            init_method = "env://"
+        else:
+            init_method = f"tcp://127.0.0.1:{port}"
+        kw = {}
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            dev = device_ids[local] if device_ids else local
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, init_method=init_method, world_size=tp_size, rank=rank,
+                                timeout=datetime.timedelta(seconds=120), **kw)
+    assert dist.get_world_size() == tp_size, "world size must equal tp_size (pipeline stages are not built)"
+    _TP_GROUP, _TP_RANK, _TP_SIZE = dist.group.WORLD, dist.get_rank(), tp_size
+    return _TP_RANK
+
+
+def tp_rank() -> int:
+    return _TP_RANK
+
+
+def tp_size() -> int:
+    return _TP_SIZE
+
+
+def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    if _TP_SIZE > 1:
+        dist.all_reduce(x, group=_TP_GROUP)
+    return x
+
+
+def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
+    """Concatenate the ranks' shards along the last dimension."""
+    if _TP_SIZE == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=_TP_GROUP)
+    return out.movedim(0, -2).reshape(x.shape[:-1] + (_TP_SIZE * x.shape[-1],))
+
+
+def tp_broadcast(x: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if _TP_SIZE > 1:
+        dist.broadcast(x, src=src, group=_TP_GROUP)
+    return x
+
+
+def tp_all_gather_min_int(value: int, device) -> int:
+    """Smallest `value` over the ranks (KV pool sizing, model_runner.py:166-169)."""
+    if _TP_SIZE == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+    return int(t.item())
+
+
+def barrier():
+    if _TP_SIZE > 1:
+        dist.barrier(group=_TP_GROUP)
+
+
+def shutdown():
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1

@@ -1,0 +1,19 @@
+"""RMSNorm module backed by the HIP kernel (interface of nanovllmx/layers/layernorm.py:6-36)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):
+        """y = x * rsqrt(mean(x^2) + eps) * weight in fp32, rounded once; with `residual`, x + residual is
+        normalised unrounded and returned rounded as the new residual: (y, residual)."""
+        return ops.rmsnorm(x, self.weight, self.variance_epsilon, residual)

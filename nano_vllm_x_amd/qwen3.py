@@ -1,0 +1,306 @@
+"""Qwen3 decoder stack: the caller that hosts the hot-path ops.
+
+Op order, shard rules and weight-name mapping follow nanovllmx/models/qwen3.py (attention block
+:117-136, decoder layer :167-188, stack :249-268, logits :295-300, stacked weights :310-348) and
+the parallel linears of nanovllmx/layers/linear.py (:387-408 qkv shards, :488-498 merged-column
+shards) and vocab_parallel_embedding.py (:93-108 masked embedding + all-reduce, :147-151 LM head
+all-gather).  Dense projections stay library GEMMs (torch -> hipBLASLt); everything between them
+is a HIP kernel of this package: RMSNorm(+residual), fused q/k-norm + rotary + KV scatter, paged
+attention, SiluAndMul.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, fields
+from typing import Iterable, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import distributed as tpd
+from . import ops
+from .layers.activation import SiluAndMul
+from .layers.attention import Attention
+from .layers.layernorm import RMSNorm
+from .layers.rotary_embedding import RotaryEmbedding, build_cos_sin_cache
+
+
+@dataclass
+class Qwen3Config:
+    vocab_size: int = 151936
+    hidden_size: int = 1024
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    max_position_embeddings: int = 40960
+    rope_theta: float = 1000000.0
+    tie_word_embeddings: bool = True
+    torch_dtype: str = "bfloat16"
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "Qwen3Config":
+        known = {f.name for f in fields(cls)}
+        kw = {k: v for k, v in d.items() if k in known}
+        if "torch_dtype" not in kw and "dtype" in d:
+            kw["torch_dtype"] = d["dtype"]
+        if "head_dim" not in kw and "hidden_size" in kw and "num_attention_heads" in kw:
+            kw["head_dim"] = kw["hidden_size"] // kw["num_attention_heads"]
+        return cls(**kw)
+
+
+# public model-card geometry (no config.json is reachable offline)
+PRESETS = {
+    "Qwen3-0.6B": dict(hidden_size=1024, intermediate_size=3072, num_hidden_layers=28, num_attention_heads=16,
+                       num_key_value_heads=8, tie_word_embeddings=True),
+    "Qwen3-8B": dict(hidden_size=4096, intermediate_size=12288, num_hidden_layers=36, num_attention_heads=32,
+                     num_key_value_heads=8, tie_word_embeddings=False),
+    "Qwen3-32B": dict(hidden_size=5120, intermediate_size=25600, num_hidden_layers=64, num_attention_heads=64,
+                      num_key_value_heads=8, tie_word_embeddings=False),
+}
+
+
+def load_config(model: str) -> Qwen3Config:
+    """`model` is a directory holding config.json, or the name of a preset (possibly as the last
+    path component, e.g. "../Qwen3-0.6B" as the reference's bench.py passes it)."""
+    cfg_file = os.path.join(model, "config.json")
+    if os.path.isfile(cfg_file):
+        with open(cfg_file) as f:
+            return Qwen3Config.from_dict(json.load(f))
+    name = os.path.basename(os.path.normpath(model))
+    if name in PRESETS:
+        return Qwen3Config(**PRESETS[name])
+    raise FileNotFoundError(f"{cfg_file} not found and {name!r} is not one of {sorted(PRESETS)}")
+
+
+def _shard(n: int, parts: int) -> int:
+    assert n % parts == 0, f"{n} is not divisible by tensor-parallel size {parts}"
+    return n // parts
+
+
+class Qwen3Attention(nn.Module):
+    def __init__(self, cfg: Qwen3Config, layer_id: int, rope_table: torch.Tensor):
+        super().__init__()
+        tp = tpd.tp_size()
+        self.total_heads, self.total_kv_heads, self.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.num_heads = _shard(self.total_heads, tp)
+        if self.total_kv_heads >= tp:
+            self.num_kv_heads, self.kv_replicas = _shard(self.total_kv_heads, tp), 1
+        else:   # fewer kv heads than ranks: replicate (linear.py:333-338)
+            self.num_kv_heads, self.kv_replicas = 1, _shard(tp, self.total_kv_heads)
+        self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
+        self.eps = cfg.rms_norm_eps
+        self.qkv_proj = nn.Linear(cfg.hidden_size, self.q_size + 2 * self.kv_size, bias=False)
+        self.o_proj = nn.Linear(self.q_size, cfg.hidden_size, bias=False)
+        self.q_norm = RMSNorm(self.head_dim, eps=cfg.rms_norm_eps)
+        self.k_norm = RMSNorm(self.head_dim, eps=cfg.rms_norm_eps)
+        self.attn = Attention(self.num_heads, self.head_dim, self.head_dim ** -0.5, num_kv_heads=self.num_kv_heads,
+                              layer_id=layer_id)
+        self.rope_table = rope_table     # shared fp32 (max_pos, 128) buffer, not a parameter
+        self.rotary_emb: Optional[RotaryEmbedding] = None   # built on demand for the unfused path
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, fused: bool = True) -> torch.Tensor:
+        qkv = self.qkv_proj(hidden_states)
+        md = self.attn.attention_metadata
+        if fused:
+            k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
+            q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
+                                      md.output_kv_indices, k_cache, v_cache, self.num_heads, self.num_kv_heads)
+            attn_out = self.attn(q, None, None)
+        else:   # op by op, as the reference's module graph runs it (qwen3.py:122-134)
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            t = q.shape[0]
+            q = self.q_norm(q.reshape(t, self.num_heads, self.head_dim)).view(t, self.q_size)
+            k = self.k_norm(k.reshape(t, self.num_kv_heads, self.head_dim)).view(t, self.kv_size)
+            q, k = ops.rope(positions, q, k, self.rope_table)
+            attn_out = self.attn(q, k, v.contiguous())
+        out = self.o_proj(attn_out)
+        return tpd.tp_all_reduce(out)
+
+
+class Qwen3MLP(nn.Module):
+    def __init__(self, cfg: Qwen3Config):
+        super().__init__()
+        inter = _shard(cfg.intermediate_size, tpd.tp_size())
+        self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * inter, bias=False)
+        self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        return tpd.tp_all_reduce(self.down_proj(self.act_fn(self.gate_up_proj(x))))
+
+
+class Qwen3DecoderLayer(nn.Module):
+    def __init__(self, cfg: Qwen3Config, layer_id: int, rope_table: torch.Tensor):
+        super().__init__()
+        self.self_attn = Qwen3Attention(cfg, layer_id, rope_table)
+        self.mlp = Qwen3MLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, residual, fused: bool = True):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, fused)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
+
+
+class VocabParallelEmbedding(nn.Module):
+    """Rows [rank*V/tp, (rank+1)*V/tp) of the (64-padded) vocabulary; other ids contribute zeros and the
+    ranks' partial rows are summed (vocab_parallel_embedding.py:56-108)."""
+
+    def __init__(self, vocab: int, hidden: int):
+        super().__init__()
+        tp = tpd.tp_size()
+        self.vocab = vocab
+        padded = ((vocab + 63) // 64) * 64
+        self.per_rank = _shard(padded, tp)
+        self.start = self.per_rank * tpd.tp_rank()
+        self.weight = nn.Parameter(torch.empty(self.per_rank, hidden))
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        if tpd.tp_size() == 1:
+            return F.embedding(ids, self.weight)
+        local = ids - self.start
+        mine = (local >= 0) & (local < self.per_rank)
+        out = F.embedding(torch.where(mine, local, torch.zeros_like(local)), self.weight)
+        out.masked_fill_(~mine.unsqueeze(-1), 0)
+        return tpd.tp_all_reduce(out)
+
+
+class Qwen3Model(nn.Module):
+    def __init__(self, cfg: Qwen3Config):
+        super().__init__()
+        self.config = cfg
+        self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
+        self.register_buffer("rope_table", build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta),
+                             persistent=False)
+        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, i, self.rope_table) for i in range(cfg.num_hidden_layers))
+        self.norm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+
+    def forward(self, input_ids, positions, fused: bool = True):
+        hidden_states, residual = self.embed_tokens(input_ids), None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, residual, fused)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class Qwen3ForCausalLM(nn.Module):
+    # (fused parameter, checkpoint name, shard id) -- qwen3.py:312-319
+    STACKED = [("qkv_proj", "q_proj", "q"), ("qkv_proj", "k_proj", "k"), ("qkv_proj", "v_proj", "v"),
+               ("gate_up_proj", "gate_proj", 0), ("gate_up_proj", "up_proj", 1)]
+
+    def __init__(self, cfg: Qwen3Config):
+        super().__init__()
+        self.config = cfg
+        self.model = Qwen3Model(cfg)
+        self.lm_head = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
+        self.fused = True
+
+    def finalize(self):
+        """Call after .to(device, dtype): restore the fp32 rotary table and share it with every layer
+        (module-wide casts touch buffers), tie the LM head when the checkpoint says so."""
+        m = self.model
+        dev = m.embed_tokens.weight.device
+        m.rope_table = build_cos_sin_cache(self.config.head_dim, self.config.max_position_embeddings,
+                                           self.config.rope_theta).to(dev)
+        for layer in m.layers:
+            layer.self_attn.rope_table = m.rope_table
+        if self.config.tie_word_embeddings:
+            self.lm_head.weight = m.embed_tokens.weight
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        return self.model(input_ids, positions, self.fused)
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        logits = tpd.tp_all_gather_last_dim(F.linear(hidden_states, self.lm_head.weight))
+        return logits[..., :self.config.vocab_size]
+
+    # -- weights ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def init_random(self, seed: int = 0):
+        """Seeded random weights of the right shapes (no checkpoint exists offline).  Each full matrix
+        is drawn from the same stream on every rank and then sharded, so TP=N computes the same
+        function as TP=1."""
+        cfg = self.config
+        dev = self.model.embed_tokens.weight.device
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+
+        def full(rows, cols, std):
+            return (torch.randn(rows, cols, generator=gen) * std)
+
+        def vec(n):
+            return 1.0 + 0.1 * torch.randn(n, generator=gen)
+
+        h, d = cfg.hidden_size, cfg.head_dim
+        weights = [("model.embed_tokens.weight", full(cfg.vocab_size, h, 0.05)), ("model.norm.weight", vec(h))]
+        if not cfg.tie_word_embeddings:
+            weights.append(("lm_head.weight", full(cfg.vocab_size, h, h ** -0.5)))
+        self.load_weights(weights)
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            self.load_weights([
+                (p + "self_attn.q_proj.weight", full(cfg.num_attention_heads * d, h, h ** -0.5)),
+                (p + "self_attn.k_proj.weight", full(cfg.num_key_value_heads * d, h, h ** -0.5)),
+                (p + "self_attn.v_proj.weight", full(cfg.num_key_value_heads * d, h, h ** -0.5)),
+                (p + "self_attn.o_proj.weight", full(h, cfg.num_attention_heads * d, (cfg.num_attention_heads * d) ** -0.5)),
+                (p + "self_attn.q_norm.weight", vec(d)), (p + "self_attn.k_norm.weight", vec(d)),
+                (p + "mlp.gate_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)),
+                (p + "mlp.up_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)),
+                (p + "mlp.down_proj.weight", full(h, cfg.intermediate_size, cfg.intermediate_size ** -0.5)),
+                (p + "input_layernorm.weight", vec(h)), (p + "post_attention_layernorm.weight", vec(h)),
+            ])
+        del dev
+
+    @torch.no_grad()
+    def load_weights(self, weights: Iterable):
+        """Checkpoint tensors (HF names, full size) -> this rank's fused, sharded parameters."""
+        params = dict(self.named_parameters())
+        tp, rank = tpd.tp_size(), tpd.tp_rank()
+        for name, w in weights:
+            for fused_name, ckpt_name, shard_id in self.STACKED:
+                if ckpt_name in name:
+                    target = params[name.replace(ckpt_name, fused_name)]
+                    self._load_stacked(target, w, shard_id, name, tp, rank)
+                    break
+            else:
+                if name not in params:
+                    if name == "lm_head.weight" and self.config.tie_word_embeddings:
+                        continue
+                    continue
+                p = params[name]
+                if name.endswith("embed_tokens.weight") or name == "lm_head.weight":
+                    per = p.shape[0]
+                    rows = w[rank * per:(rank + 1) * per]
+                    p[:rows.shape[0]].copy_(rows)
+                    p[rows.shape[0]:].zero_()
+                elif name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+                    per = p.shape[1]   # row-parallel: shard the input dimension
+                    p.copy_(w[:, rank * per:(rank + 1) * per])
+                else:
+                    p.copy_(w)
+
+    def _load_stacked(self, target, w, shard_id, name, tp, rank):
+        layer = self.model.layers[int(name.split("layers.")[1].split(".")[0])]
+        if shard_id in ("q", "k", "v"):
+            a = layer.self_attn
+            d = a.head_dim
+            if shard_id == "q":
+                off, size, idx = 0, a.num_heads * d, rank
+            elif shard_id == "k":
+                off, size, idx = a.num_heads * d, a.num_kv_heads * d, rank // a.kv_replicas
+            else:
+                off, size, idx = (a.num_heads + a.num_kv_heads) * d, a.num_kv_heads * d, rank // a.kv_replicas
+        else:
+            size = target.shape[0] // 2
+            off, idx = shard_id * size, rank
+        target[off:off + size].copy_(w[idx * size:(idx + 1) * size])
