@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the reference's bench.py workload (256 requests, Qwen3-0.6B) on MI355X.
+
+A "step" is one full pass of the workload through `LLM.generate` (the reference's bench.py:13-45:
+seed 0, 256 prompts of U[100,1024] random token ids, max_tokens U[100,1024], temperature 0.6,
+ignore_eos, max_bs 256, context 4096, gpu_memory_utilization 0.8), all requests submitted at once.
+`value` follows bench.py:43-44: sum(max_tokens) / wall.  NB the engine treats max_tokens as a cap on
+prompt + generated length (engine.py:149), so the tokens actually generated are fewer; both rates
+are reported (`value` = nominal, `generated_tokens_per_s` = real).
+
+python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, TP = N)
+
+Also in the JSON line:
+  roofline      -- the dominant hand-written kernel (paged decode attention), replayed on the decode
+                   batches of this workload with HIP events on the launch stream; algorithmic bytes =
+                   kv_rows * 2 (K,V) * kv_heads * 128 * 2 B + q/o rows + 4 B per block-table entry.
+  cpu_baseline  -- the CPU oracle engine (oracle/, a port of the same path) on a bounded sample of the
+                   same workload, timed on this box's host cores (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+METRIC = "output tokens/s (whole node), bench.py 256-req synthetic, Qwen3-0.6B @1/2/4/8 GPU"
+A100_PUBLISHED = 9032.37   # tok/s, 1x A100 40GB, reference README.md:100 (other hardware)
+HBM_PEAK_GBS = 8000.0
+
+
+def workload(num_seqs: int, max_in: int = 1024, max_out: int = 1024, seed: int = 0):
+    """bench.py:13-31 with the same RNG call order."""
+    rnd = random.Random()
+    rnd.seed(seed)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(100, max_in))] for _ in range(num_seqs)]
+    max_tokens = [rnd.randint(100, max_out) for _ in range(num_seqs)]
+    return prompts, max_tokens
+
+
+async def one_pass(llm, prompts, max_tokens):
+    from nano_vllm_x_amd import SamplingParams
+
+    async def consume(i, p, m):
+        n = 0
+        async for _ in llm.generate(list(p), SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m), sequence_id=f"req{i}"):
+            n += 1
+        return n
+
+    counts = await asyncio.gather(*(consume(i, p, m) for i, (p, m) in enumerate(zip(prompts, max_tokens))))
+    return sum(counts)
+
+
+def sync_all(world: int):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------
+def decode_batches_of_workload(prompts, max_tokens, kv_size, max_bs, context_len, every: int):
+    """Replay the scheduler alone (token value is irrelevant to it) and keep every `every`-th decode
+    batch's block table: (kv_lens, flat slot list)."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    core = EngineCore(kv_cache_size=kv_size, max_bs=max_bs, context_len=context_len)
+    for i, (p, m) in enumerate(zip(prompts, max_tokens)):
+        core.add_sequence(f"r{i}", list(p), SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m))
+    kept, n_dec, kv_rows_total = [], 0, 0
+    while core.has_unfinished_sequences():
+        b = core.scheduler.schedule()
+        if b.forward_mode == ForwardMode.DECODE:
+            lens = [len(s.kv_indices) for s in b.seqs]
+            kv_rows_total += sum(lens)
+            if n_dec % every == 0:
+                kept.append((np.asarray(lens, dtype=np.int32),
+                             np.concatenate([np.asarray(s.kv_indices, dtype=np.int32) for s in b.seqs])))
+            n_dec += 1
+        core.update_from_output(b, [7] * b.num_seqs)
+    return kept, n_dec, kv_rows_total
+
+
+def decode_attention_roofline(runner, batches, reps: int = 3):
+    """Time nvx_paged_decode (+ its merge kernel) on the kept decode batches with HIP events on the
+    stream the kernels are launched on (torch's current stream).  Consecutive launches use different
+    layers of the real KV pool so that no launch finds its rows in the Infinity Cache."""
+    from nano_vllm_x_amd import ops
+
+    dev = runner.device
+    hq, hkv, layers = runner.num_heads, runner.num_kv_heads, runner.num_layers
+    ws = ops.DecodeWorkspace(runner.max_bs, hq, hkv, dev)
+    kc, vc = runner.kv_cache.k_cache, runner.kv_cache.v_cache
+    total_bytes = total_ms = 0.0
+    launches = 0
+    layer = 0
+    for lens, flat in batches:
+        b = len(lens)
+        kv_len = torch.from_numpy(lens).to(dev)
+        kv_start = torch.from_numpy(np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.int64)).to(dev)
+        idx = torch.from_numpy(flat).to(dev)
+        q = torch.randn(b, hq * 128, device=dev, dtype=torch.bfloat16)
+        out = torch.empty_like(q)
+        ops.decode_plan(kv_len, ws)
+        rows = int(lens.sum())
+        alg = rows * 2 * hkv * 128 * 2 + 2 * b * hq * 128 * 2 + 4 * rows
+        for r in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.paged_decode(q, kc[layer], vc[layer], idx, kv_start, kv_len, ws, 128 ** -0.5, out=out)
+            e1.record()
+            e1.synchronize()
+            layer = (layer + 1) % layers
+            if r == 0:
+                continue   # first launch of a batch shape: untimed
+            total_ms += e0.elapsed_time(e1)
+            total_bytes += alg
+            launches += 1
+    achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("paged_decode_kernel"),
+            "kernel": "paged_decode_kernel (+decode_merge_kernel)", "launches": launches,
+            "avg_launch_us": round(total_ms * 1e3 / max(1, launches), 2),
+            "avg_algorithmic_bytes": int(total_bytes / max(1, launches))}
+
+
+def _pmc_traffic(kernel: str):
+    """HBM bytes per launch from rocprofv3 PMC passes, if a summary has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    return None
+
+
+def cpu_baseline(prompts, max_tokens, n_req: int, new_tokens: int):
+    """Oracle engine on host cores over the first `n_req` requests, generation capped to `new_tokens`."""
+    from nano_vllm_x_amd.qwen3 import PRESETS, Qwen3Config
+    from oracle.qwen3_oracle import cpu_engine_run_oracle
+
+    cfg = Qwen3Config(**PRESETS["Qwen3-0.6B"]).__dict__
+    ps = prompts[:n_req]
+    ms = [min(m, len(p) + new_tokens) for p, m in zip(ps, max_tokens[:n_req])]
+    r = cpu_engine_run_oracle(cfg, ps, ms, kv_slots=sum(max(m, len(p) + 1) for p, m in zip(ps, ms)) + 64, max_bs=256, context_len=4096, dtype=torch.float32)
+    return {"value": round(r["nominal_tokens"] / r["wall_s"], 2), "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"first {n_req} requests of the same workload, max_tokens capped at prompt+{new_tokens}; fp32 weights; "
+                      f"{r['steps']} engine steps, {r['generated']} generated tokens, {r['wall_s']:.1f} s wall "
+                      f"({r['generated'] / r['wall_s']:.2f} generated tok/s)",
+            "host_cpus": os.cpu_count()}
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-seqs", type=int, default=256)
+    ap.add_argument("--model", default="Qwen3-0.6B")
+    ap.add_argument("--max-bs", type=int, default=256)
+    ap.add_argument("--context-len", type=int, default=4096)
+    ap.add_argument("--kv-cache-size", type=int, default=0, help="0 = size from free memory * 0.8, as the reference does")
+    ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-requests", type=int, default=4)
+    ap.add_argument("--cpu-new-tokens", type=int, default=16)
+    ap.add_argument("--roofline-every", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    from nano_vllm_x_amd import LLM
+
+    prompts, max_tokens = workload(args.num_seqs)
+    t_init = time.perf_counter()
+    kv_size = args.kv_cache_size or None
+    if kv_size is None and world > 1:
+        # per-rank KV bytes shrink with TP; keep the slot count a host can index (a few million)
+        kv_size = 4_000_000
+    llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
+              context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size)
+    init_s = time.perf_counter() - t_init
+    eng = llm.engine
+
+    for _ in range(args.warmup):
+        eng.reset()
+        asyncio.run(one_pass(llm, prompts, max_tokens))
+    sync_all(world)
+    stats0 = dict(eng.model_runner.stats)
+    t0 = time.perf_counter()
+    generated = 0
+    for _ in range(args.steps):
+        eng.reset()
+        generated += asyncio.run(one_pass(llm, prompts, max_tokens))
+    sync_all(world)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device=eng.model_runner.device)
+        torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+        wall = float(w.item())
+    stats1 = eng.model_runner.stats
+    nominal = sum(max_tokens) * args.steps
+
+    result = {
+        "metric": METRIC, "value": round(nominal / wall, 2), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": round(nominal / wall / A100_PUBLISHED, 3),
+        "dtype": "bf16", "data": "synthetic (random token ids, seed 0; random-init weights of the Qwen3-0.6B architecture)",
+        "config": {"workload": f"reference bench.py: {args.num_seqs} requests, prompt U[100,1024], max_tokens U[100,1024], "
+                               "temperature 0.6, ignore_eos, all submitted at once",
+                   "model": args.model, "parallelism": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
+                   "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph"},
+        "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
+        "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
+        "engine_steps": {k: stats1[k] - stats0[k] for k in stats1}, "init_s": round(init_s, 1),
+        "vs_baseline_note": "reference README: 9032.37 tok/s on 1x A100 40GB (other hardware)",
+    }
+
+    if rank == 0 and not args.no_roofline:
+        batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
+                                                             args.context_len, args.roofline_every)
+        result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
+        result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x3 launches"
+        result["decode_kv_rows_per_step"] = kv_rows
+    if world > 1:
+        torch.distributed.barrier()
+    llm.shutdown()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del llm, eng
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(prompts, max_tokens, args.cpu_requests, args.cpu_new_tokens)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()
