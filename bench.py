@@ -92,7 +92,7 @@ def decode_batches_of_workload(prompts, max_tokens, kv_size, max_bs, context_len
     return kept, n_dec, kv_rows_total
 
 
-def decode_attention_roofline(runner, batches, reps: int = 3):
+def decode_attention_roofline(runner, batches, reps: int = 8):
     """Time nvx_paged_decode (+ its merge kernel) on the kept decode batches with HIP events on the
     stream the kernels are launched on (torch's current stream).  Consecutive launches use different
     layers of the real KV pool so that no launch finds its rows in the Infinity Cache."""
@@ -115,18 +115,20 @@ def decode_attention_roofline(runner, batches, reps: int = 3):
         ops.decode_plan(kv_len, ws)
         rows = int(lens.sum())
         alg = rows * 2 * hkv * 128 * 2 + 2 * b * hq * 128 * 2 + 4 * rows
-        for r in range(reps + 1):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        # one untimed launch, then `reps` launches back to back between one pair of events: a lone
+        # 30-microsecond kernel between two events would mostly measure the launch gap around it
+        ops.paged_decode(q, kc[layer], vc[layer], idx, kv_start, kv_len, ws, 128 ** -0.5, out=out)
+        layer = (layer + 1) % layers
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
             ops.paged_decode(q, kc[layer], vc[layer], idx, kv_start, kv_len, ws, 128 ** -0.5, out=out)
-            e1.record()
-            e1.synchronize()
             layer = (layer + 1) % layers
-            if r == 0:
-                continue   # first launch of a batch shape: untimed
-            total_ms += e0.elapsed_time(e1)
-            total_bytes += alg
-            launches += 1
+        e1.record()
+        e1.synchronize()
+        total_ms += e0.elapsed_time(e1)
+        total_bytes += alg * reps
+        launches += reps
     achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("paged_decode_kernel"),
@@ -175,8 +177,8 @@ def main():
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-requests", type=int, default=4)
-    ap.add_argument("--cpu-new-tokens", type=int, default=16)
+    ap.add_argument("--cpu-requests", type=int, default=8)
+    ap.add_argument("--cpu-new-tokens", type=int, default=48)
     ap.add_argument("--roofline-every", type=int, default=8)
     args = ap.parse_args()
 
@@ -238,7 +240,7 @@ def main():
         batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
                                                              args.context_len, args.roofline_every)
         result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
-        result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x3 launches"
+        result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x8 launches over rotating layers"
         result["decode_kv_rows_per_step"] = kv_rows
     if world > 1:
         torch.distributed.barrier()
