@@ -112,17 +112,17 @@ def decode_attention_roofline(runner, batches, reps: int = 8):
         idx = torch.from_numpy(flat).to(dev)
         q = torch.randn(b, hq * 128, device=dev, dtype=torch.bfloat16)
         out = torch.empty_like(q)
-        ops.decode_plan(kv_len, ws)
+        ops.decode_plan(kv_len, kv_start, ws)
         rows = int(lens.sum())
         alg = rows * 2 * hkv * 128 * 2 + 2 * b * hq * 128 * 2 + 4 * rows
         # one untimed launch, then `reps` launches back to back between one pair of events: a lone
         # 30-microsecond kernel between two events would mostly measure the launch gap around it
-        ops.paged_decode(q, kc[layer], vc[layer], idx, kv_start, kv_len, ws, 128 ** -0.5, out=out)
+        ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
         layer = (layer + 1) % layers
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for r in range(reps):
-            ops.paged_decode(q, kc[layer], vc[layer], idx, kv_start, kv_len, ws, 128 ** -0.5, out=out)
+            ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
             layer = (layer + 1) % layers
         e1.record()
         e1.synchronize()

@@ -101,23 +101,24 @@ int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t s
  * A CSR table (attention.py:84-101) is the case kv_start = indptr[:-1], kv_len = diff(indptr).
  *
  * nvx_decode_plan splits every sequence into chunks of one common length so that the launch
- * fills the chip, and writes the work list into plan_ws (int32, >= nvx_decode_plan_ws_ints()).
- * It runs on the device (no host sync) and is part of the captured graph; call it once per
- * step, then nvx_paged_decode once per layer.
+ * fills the chip, and writes the work list (one 32-byte record per chunk, holding the chunk's
+ * absolute position in kv_indices) into plan_ws (int32, >= nvx_decode_plan_ws_ints(), 16-byte
+ * aligned).  It runs on the device (no host sync) and is part of the captured graph; call it
+ * once per step, then nvx_paged_decode once per layer with the same kv_indices.
  *
  * nvx_paged_decode: q (batch, n_q_heads, 128) bf16 rows q_row_stride apart; k_cache/v_cache
  * (n_slots, n_kv_heads, 128) bf16 of one layer; out (batch, n_q_heads, 128) bf16 contiguous.
  * softmax(q.k * sm_scale) in fp32.  partial_ws: fp32 scratch for split sequences,
- * >= nvx_decode_partial_ws_floats() floats.  Rows with kv_len <= 0 produce zeros. */
+ * >= nvx_decode_partial_ws_floats() floats.  Rows with kv_len <= 0 produce zeros; slot ids outside
+ * [0, n_slots) are treated as masked keys. */
 int64_t nvx_decode_plan_ws_ints(int64_t max_batch, int n_kv_heads);
 int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads, int n_kv_heads);
-int nvx_decode_plan(const int32_t* kv_len, int64_t batch, int n_kv_heads, int32_t* plan_ws,
-                    int64_t plan_ws_ints, nvx_stream_t stream);
+int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, int64_t batch, int n_kv_heads,
+                    int32_t* plan_ws, int64_t plan_ws_ints, nvx_stream_t stream);
 int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
-                     int64_t n_slots, const int32_t* kv_indices, const int64_t* kv_start,
-                     const int32_t* kv_len, const int32_t* plan_ws, float* partial_ws,
-                     void* out, int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale,
-                     nvx_stream_t stream);
+                     int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws,
+                     float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                     float sm_scale, nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Paged attention, prefill: causal, variable-length, queries right-aligned to the keys.

@@ -195,7 +195,7 @@ class ModelRunner:
         bt = self.block_table
         ops.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
                               bt.positions, bt.input_ids)
-        ops.decode_plan(bt.kv_len[:bs], self.decode_ws)
+        ops.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], self.decode_ws)
         wrapper = self._graph_wrappers[bs]
         md = AttentionMetadata(forward_mode=ForwardMode.DECODE, kv_cache=self.kv_cache, output_kv_indices=bt.out_slots[:bs],
                                wrapper=wrapper)

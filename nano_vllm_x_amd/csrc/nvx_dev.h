@@ -54,9 +54,17 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
 }
-// reductions across the 16 lanes of one quarter-wave (lanes 16g .. 16g+15)
+// Sum across the 16 lanes of one quarter-wave (a DPP "row": lanes 16g .. 16g+15); every lane ends with
+// the row total.  DPP moves ride on the VALU add itself (v_add_f32_dpp); __shfl_xor would compile to
+// ds_bpermute_b32, a round trip through the LDS crossbar per step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float quarter_sum(float v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_move<0x141>(v);   // row_half_mirror: quad 0 <-> quad 1, quad 2 <-> quad 3
+    v += dpp_move<0x140>(v);   // row_mirror: lower 8 <-> upper 8
     return v;
 }

@@ -131,7 +131,7 @@ class PagedDecodeWrapper:
         self._kv_start[:b].copy_(indptr[:-1])
         torch.sub(indptr[1:], indptr[:-1], out=self._kv_len[:b])
         self._kv_indices = indices if not self._static or self._indices_buf is None else self._indices_buf
-        ops.decode_plan(self._kv_len[:b], self._ws)
+        ops.decode_plan(self._kv_len[:b], self._kv_start[:b], self._ws)
 
     def bind_table(self, kv_indices, kv_start, kv_len, batch: int, ws: ops.DecodeWorkspace):
         """Use caller-owned static buffers (the device-resident block table); the plan kernel is then
@@ -142,8 +142,8 @@ class PagedDecodeWrapper:
         k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)
         b = self._batch
         hq = self._ws.n_q_heads
-        o = ops.paged_decode(q.reshape(b, hq * 128), k_cache, v_cache, self._kv_indices, self._kv_start[:b], self._kv_len[:b],
-                             self._ws, self._sm_scale if self._sm_scale is not None else 128 ** -0.5, out=out)
+        o = ops.paged_decode(q.reshape(b, hq * 128), k_cache, v_cache, self._kv_indices, b, self._ws,
+                             self._sm_scale if self._sm_scale is not None else 128 ** -0.5, out=out)
         return o.view(b, hq, 128)
 
 

@@ -151,34 +151,37 @@ class DecodeWorkspace:
                                    device=device)
 
 
-def decode_plan(kv_len, ws: DecodeWorkspace):
-    _dev(kv_len)
+def decode_plan(kv_len, kv_start, ws: DecodeWorkspace):
+    """Cut the batch's sequences into chunks (device side); must precede paged_decode of the same step."""
+    _dev(kv_len, kv_start)
     b = kv_len.numel()
     _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and 0 < b <= ws.max_batch, "decode_plan: kv_len")
+    _need(kv_start.dtype == torch.int64 and kv_start.is_contiguous() and kv_start.numel() == b, "decode_plan: kv_start")
     lib = _lib.load()
-    _lib.check(lib.nvx_decode_plan(_ptr(kv_len), b, ws.n_kv_heads, _ptr(ws.plan), ws.plan.numel(), _stream()), "nvx_decode_plan")
+    _lib.check(lib.nvx_decode_plan(_ptr(kv_len), _ptr(kv_start), b, ws.n_kv_heads, _ptr(ws.plan), ws.plan.numel(), _stream()),
+               "nvx_decode_plan")
 
 
-def paged_decode(q, k_cache, v_cache, kv_indices, kv_start, kv_len, ws: DecodeWorkspace, sm_scale, out=None):
-    """q (B, Hq*128) or (B, Hq, 128); caches (slots, Hkv, 128) of one layer; plan must be current."""
-    _dev(q, k_cache, v_cache, kv_indices, kv_start, kv_len)
-    b = kv_len.numel()
+def paged_decode(q, k_cache, v_cache, kv_indices, batch: int, ws: DecodeWorkspace, sm_scale, out=None):
+    """q (B, Hq*128) or (B, Hq, 128); caches (slots, Hkv, 128) of one layer; ws.plan must hold the plan
+    of this step (decode_plan with the same kv_indices layout)."""
+    _dev(q, k_cache, v_cache, kv_indices)
+    b = batch
     hq, hkv = ws.n_q_heads, ws.n_kv_heads
     q2 = q.view(b, hq * 128)
     _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_decode: q layout")
     _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
           tuple(k_cache.shape[-2:]) == (hkv, 128) and v_cache.shape == k_cache.shape, "paged_decode: cache layout")
     _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode: kv_indices must be int32")
-    _need(kv_start.dtype == torch.int64 and kv_start.numel() == b and kv_start.is_contiguous(), "paged_decode: kv_start")
-    _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and b <= ws.max_batch, "paged_decode: kv_len")
+    _need(0 < b <= ws.max_batch, "paged_decode: batch exceeds the workspace")
     if out is None:
         out = torch.empty((b, hq * 128), dtype=BF16, device=q.device)
     else:
         _need(out.is_contiguous() and out.numel() == b * hq * 128 and out.dtype == BF16, "paged_decode: out")
     lib = _lib.load()
     _lib.check(lib.nvx_paged_decode(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
-                                    _ptr(kv_start), _ptr(kv_len), _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv,
-                                    float(sm_scale), _stream()), "nvx_paged_decode")
+                                    _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv, float(sm_scale), _stream()),
+               "nvx_paged_decode")
     return out
 
 

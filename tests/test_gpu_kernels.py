@@ -146,10 +146,14 @@ def test_fused_qknorm_rope_store_vs_unfused_oracle(ops):
     vc = torch.zeros(slots, hkv, d, dtype=torch.bfloat16, device=DEV)
     q_out = ops.qknorm_rope_store(qkv.to(DEV), pos.to(DEV), table.to(DEV), qw.to(DEV), kw.to(DEV), 1e-6, slot.to(DEV), kc, vc, hq, hkv)
     torch.cuda.synchronize()
-    # a 1-ulp difference after the norm can grow through the rotation's three roundings
-    assert bf16_ulp_diff(q_out, q_ref) <= 2
+    # a 1-ulp difference after the norm passes through the rotation, whose differences can cancel: the
+    # bound is absolute, 2 bf16 ulps of the operands' magnitude (2^-7 * max|x| of the tensor), not of the result
+    def close(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+    assert close(q_out, q_ref)
     live = slot >= 0
-    assert bf16_ulp_diff(kc.cpu()[slot[live]].reshape(-1, hkv * d), k_ref[live]) <= 2
+    assert close(kc.cpu()[slot[live]].reshape(-1, hkv * d), k_ref[live])
     assert np.array_equal(to_bits(vc.cpu()[slot[live]].reshape(-1, hkv * d)), to_bits(v[live].contiguous()))
     untouched = torch.ones(slots, dtype=torch.bool)
     untouched[slot[live]] = False
@@ -188,8 +192,8 @@ def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
         kv_indices = perm.to(DEV)
         kv_start = torch.from_numpy(indptr[:-1].astype(np.int64)).to(DEV)
     kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
-    ops.decode_plan(kv_len, ws)
-    out = ops.paged_decode(q.to(DEV).view(b, hq * 128), kc.to(DEV), vc.to(DEV), kv_indices, kv_start, kv_len, ws, 128 ** -0.5)
+    ops.decode_plan(kv_len, kv_start, ws)
+    out = ops.paged_decode(q.to(DEV).view(b, hq * 128), kc.to(DEV), vc.to(DEV), kv_indices, b, ws, 128 ** -0.5)
     torch.cuda.synchronize()
     attn_close(out.view(b, hq, 128), ref)
     return ws
@@ -219,9 +223,9 @@ def test_decode_zero_length_row_gives_zeros(ops):
     q = torch.randn(2, 16 * 128, generator=gen).to(torch.bfloat16).to(DEV)
     ws = ops.DecodeWorkspace(2, 16, 8, DEV)
     kv_len = torch.tensor([0, 3], dtype=torch.int32, device=DEV)
-    ops.decode_plan(kv_len, ws)
-    out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.arange(8, dtype=torch.int32, device=DEV),
-                           torch.tensor([0, 2], dtype=torch.int64, device=DEV), kv_len, ws, 0.1)
+    kv_start = torch.tensor([0, 2], dtype=torch.int64, device=DEV)
+    ops.decode_plan(kv_len, kv_start, ws)
+    out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.arange(8, dtype=torch.int32, device=DEV), 2, ws, 0.1)
     assert not out[0].any() and out[1].any()
 
 
@@ -256,9 +260,8 @@ def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
             row_len.append(j + off + 1)
     ws = ops.DecodeWorkspace(t, hq, hkv, DEV)
     kv_len = torch.tensor(row_len, dtype=torch.int32, device=DEV)
-    ops.decode_plan(kv_len, ws)
-    out2 = ops.paged_decode(q.to(DEV).view(t, hq * 128), kcd, vcd, perm.to(DEV),
-                            torch.tensor(row_start, dtype=torch.int64, device=DEV), kv_len, ws, 128 ** -0.5)
+    ops.decode_plan(kv_len, torch.tensor(row_start, dtype=torch.int64, device=DEV), ws)
+    out2 = ops.paged_decode(q.to(DEV).view(t, hq * 128), kcd, vcd, perm.to(DEV), t, ws, 128 ** -0.5)
     torch.cuda.synchronize()
     # two bf16 outputs of the same fp32 quantity: 1e-3 + one rounding each + the bf16 probabilities of the MFMA path
     d = (out.float() - out2.float()).abs()

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single kernels on the shapes of the bench workload (run on the GPU box).
+
+  python tools/kernel_bench.py decode  [--every 8]     paged decode attention over the workload's decode batches
+  python tools/kernel_bench.py prefill                 paged prefill attention on the workload's 256 prompts
+  python tools/kernel_bench.py sampler                 sampler on (B, 151936) logits
+
+Timing: HIP events on torch's current stream (the stream the kernels are launched on) around a run of
+back-to-back launches that rotate through the layers of a KV pool far larger than the Infinity Cache.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import bench
+from nano_vllm_x_amd import ops
+
+DEV = "cuda:0"
+HQ, HKV, LAYERS = 16, 8, 28
+
+
+def timed(fn, reps, graph=True):
+    """Seconds per call of fn.  With graph=True the `reps` calls are captured into one hipGraph and the
+    replay is timed, so short kernels are not paced by the host's launch rate."""
+    fn()
+    torch.cuda.synchronize()
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def cmd_decode(args):
+    global HQ, HKV
+    prompts, max_tokens = bench.workload(256)
+    slots = 200_000
+    batches, n_dec, kv_rows = bench.decode_batches_of_workload(prompts, max_tokens, slots, 256, 4096, args.every)
+    if args.hkv1:
+        # same bytes, but every (sequence, kv head) becomes its own sequence of contiguous 256-byte rows:
+        # isolates what the 2 KB row stride / partial-row reads cost
+        HQ, HKV = 2, 1
+        nb = []
+        for lens, flat in batches:
+            lens8 = np.repeat(lens, 8).astype(np.int32)
+            flat8 = np.arange(int(lens8.sum()), dtype=np.int32)
+            nb.append((lens8, flat8))
+        batches = nb
+        slots = 1_600_000
+    kc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    ws = ops.DecodeWorkspace(2048 if args.hkv1 else 256, HQ, HKV, DEV)
+    tot_b = tot_t = 0.0
+    rows_out = []
+    layer = [0]
+    for i, (lens, flat) in enumerate(batches):
+        b = len(lens)
+        kv_len = torch.from_numpy(lens).to(DEV)
+        kv_start = torch.from_numpy(np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.int64)).to(DEV)
+        idx = torch.from_numpy(flat).to(DEV)
+        q = torch.randn(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
+        out = torch.empty_like(q)
+        ops.decode_plan(kv_len, kv_start, ws)
+
+        def run():
+            ops.paged_decode(q, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
+            layer[0] = (layer[0] + 1) % LAYERS
+
+        t = timed(run, args.reps)
+        rows = int(lens.sum())
+        alg = rows * 2 * HKV * 128 * 2 + 2 * b * HQ * 128 * 2 + 4 * rows
+        tot_b += alg
+        tot_t += t
+        if i % max(1, len(batches) // 12) == 0:
+            rows_out.append((i * args.every, b, rows, round(t * 1e6, 1), round(alg / t / 1e9), int(ws.plan[0]), int(ws.plan[1])))
+    print("step  B  kv_rows  us  GB/s  items chunk")
+    for r in rows_out:
+        print(*r)
+    print(json.dumps({"kernel": "paged_decode(+merge)", "batches": len(batches), "avg_us": round(tot_t / len(batches) * 1e6, 2),
+                      "GBps": round(tot_b / tot_t / 1e9, 1), "frac_of_8TBps": round(tot_b / tot_t / 8e12, 4)}))
+
+
+def cmd_prefill(args):
+    prompts, _ = bench.workload(args.num_seqs)
+    lens = [len(p) for p in prompts]
+    t_tok = sum(lens)
+    slots = t_tok + 1024
+    kc = torch.randn(4, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(4, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(t_tok, HQ * 128, device=DEV, dtype=torch.bfloat16)
+    indptr = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).to(DEV)
+    idx = torch.arange(t_tok, dtype=torch.int32, device=DEV)
+    plan = ops.prefill_plan_ws(len(lens), DEV)
+    ops.prefill_plan(indptr, plan)
+    out = torch.empty_like(q)
+    layer = [0]
+
+    def run():
+        ops.paged_prefill(q, kc[layer[0]], vc[layer[0]], indptr, indptr, idx, plan, HQ, HKV, 128 ** -0.5, out=out)
+        layer[0] = (layer[0] + 1) % 4
+
+    t = timed(run, args.reps)
+    flop = 4 * HQ * 128 * sum(l * (l + 1) // 2 for l in lens)
+    print(json.dumps({"kernel": "paged_prefill", "tokens": t_tok, "ms": round(t * 1e3, 3), "TFLOPs": round(flop / t / 1e12, 1),
+                      "frac_of_2.5PF": round(flop / t / 2.5e15, 4)}))
+
+
+def cmd_sampler(args):
+    v = 151936
+    for b in (1, 29, 123, 256):
+        logits = (torch.randn(b, v, device=DEV) * 2).to(torch.bfloat16)
+        t = torch.full((b,), 0.6, device=DEV)
+        k = torch.full((b,), v, dtype=torch.int64, device=DEV)
+        p = torch.ones(b, device=DEV)
+        mp = torch.zeros(b, device=DEV)
+        out = torch.zeros(b, dtype=torch.int64, device=DEV)
+        n = [0]
+
+        def run():
+            n[0] += 1
+            ops.sample(logits, t, k, p, mp, 1, n[0], out=out)
+
+        dt = timed(run, args.reps)
+        k2 = torch.full((b,), 50, dtype=torch.int64, device=DEV)
+        p2 = torch.full((b,), 0.9, device=DEV)
+
+        def run2():
+            n[0] += 1
+            ops.sample(logits, t, k2, p2, mp, 1, n[0], out=out)
+
+        dt2 = timed(run2, max(2, args.reps // 4))
+        print(json.dumps({"kernel": "sample", "B": b, "plain_us": round(dt * 1e6, 1), "GBps": round(b * v * 2 / dt / 1e9, 1),
+                          "topk_topp_us": round(dt2 * 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler"])
+    ap.add_argument("--every", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=28)
+    ap.add_argument("--num-seqs", type=int, default=256)
+    ap.add_argument("--hkv1", action="store_true")
+    a = ap.parse_args()
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler}[a.cmd](a)
