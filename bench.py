@@ -92,7 +92,7 @@ def decode_batches_of_workload(prompts, max_tokens, kv_size, max_bs, context_len
     return kept, n_dec, kv_rows_total
 
 
-def decode_attention_roofline(runner, batches, reps: int = 8):
+def decode_attention_roofline(runner, batches, reps: int = 14):
     """Time nvx_paged_decode (+ its merge kernel) on the kept decode batches with HIP events on the
     stream the kernels are launched on (torch's current stream).  Consecutive launches use different
     layers of the real KV pool so that no launch finds its rows in the Infinity Cache."""
@@ -115,15 +115,29 @@ def decode_attention_roofline(runner, batches, reps: int = 8):
         ops.decode_plan(kv_len, kv_start, ws)
         rows = int(lens.sum())
         alg = rows * 2 * hkv * 128 * 2 + 2 * b * hq * 128 * 2 + 4 * rows
-        # one untimed launch, then `reps` launches back to back between one pair of events: a lone
-        # 30-microsecond kernel between two events would mostly measure the launch gap around it
-        ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
-        layer = (layer + 1) % layers
+        # `reps` launches over consecutive layers are captured into one hipGraph and the replay is timed
+        # with HIP events on the replay stream: launched one by one from Python, a 30-microsecond kernel
+        # pair would be paced by the host's launch rate, not by the GPU
+        def launch_all():
+            nonlocal layer
+            for _ in range(reps):
+                ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
+                layer = (layer + 1) % layers
+
+        launch_all()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                launch_all()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for r in range(reps):
-            ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
-            layer = (layer + 1) % layers
+        graph.replay()
         e1.record()
         e1.synchronize()
         total_ms += e0.elapsed_time(e1)
@@ -239,8 +253,9 @@ def main():
     if rank == 0 and not args.no_roofline:
         batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
                                                              args.context_len, args.roofline_every)
-        result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
-        result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x8 launches over rotating layers"
+        with torch.inference_mode():   # the KV pool was allocated under inference mode
+            result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
+        result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x14 graph-replayed launches over rotating layers"
         result["decode_kv_rows_per_step"] = kv_rows
     if world > 1:
         torch.distributed.barrier()

@@ -67,8 +67,9 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     if _TP_SIZE == 1:
         return x
     x = x.contiguous()
-    out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x, group=_TP_GROUP)
+    flat = torch.empty(_TP_SIZE * x.numel(), dtype=x.dtype, device=x.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(flat, x.view(-1), group=_TP_GROUP)
+    out = flat.view((_TP_SIZE,) + tuple(x.shape))
     return out.movedim(0, -2).reshape(x.shape[:-1] + (_TP_SIZE * x.shape[-1],))
 
 

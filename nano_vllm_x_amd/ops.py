@@ -3,7 +3,8 @@
 PyTorch is used here only as the owner of device memory and of the current HIP stream; every
 function validates shapes on the host (a kernel that is handed a wrong shape faults the GPU), then
 makes exactly one call into libnvx_hip.so on `torch.cuda.current_stream()`, which makes all of them
-capturable into a hipGraph.  The same functions are registered as `torch.ops.nvx.*` custom ops.
+capturable into a hipGraph.  `nano_vllm_x_amd.torch_ops` registers the stateless ones as
+`torch.ops.nvx.*` custom ops.
 """
 from __future__ import annotations
 

@@ -383,3 +383,19 @@ def test_bad_arguments_raise(ops):
         ops.rmsnorm(x, torch.ones(100, dtype=torch.bfloat16, device=DEV), 1e-6)
     with pytest.raises(RuntimeError):
         ops.silu_mul(torch.zeros(4, 10, dtype=torch.bfloat16))   # CPU tensor: no fallback
+
+
+# -----------------------------------------------------------------------------------------------
+def test_torch_ops_namespace_calls_the_same_kernels(ops):
+    import nano_vllm_x_amd.torch_ops  # noqa: F401  (registers torch.ops.nvx.*)
+
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(7, 512, generator=gen).to(torch.bfloat16).to(DEV)
+    assert torch.equal(torch.ops.nvx.silu_mul(x), ops.silu_mul(x))
+    w = torch.randn(512, generator=gen).to(torch.bfloat16).to(DEV)
+    assert torch.equal(torch.ops.nvx.rmsnorm(x, w, 1e-6), ops.rmsnorm(x, w, 1e-6))
+    y0, r0 = ops.rmsnorm(x, w, 1e-6, residual=x.clone())
+    y1, r1 = torch.ops.nvx.rmsnorm_residual(x, x.clone(), w, 1e-6)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.nvx.silu_mul(x.cpu())   # no CPU kernel is registered
