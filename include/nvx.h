@@ -149,13 +149,17 @@ int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void* k_cache, 
  * distribution, reproducible for a given (seed, offset), not bit-comparable with
  * torch.multinomial.  out_ids: int64 (batch).  Equal scores are ordered by token id wherever the
  * reference's sort order decides (top-p boundary), as a stable ascending sort does.
- * No sort and no scratch memory: thresholds come from radix selection over the row.
+ * No sort: thresholds come from radix selection over the row.
+ * ws (optional, may be NULL): >= nvx_sample_ws_bytes(batch) bytes, 8-byte aligned.  With it, rows
+ * that have no active filter are cut into slices processed by several workgroups each (the draw is
+ * the same token either way); without it every row is one workgroup.
  * nvx_sampler_probs writes the masked, renormalised distribution itself (fp32 (batch, vocab)):
  * the part of the reference computation that is comparable up to fp32 rounding. */
+int64_t nvx_sample_ws_bytes(int64_t max_batch);
 int nvx_sample(const void* logits, int logits_is_f32, int64_t logits_row_stride,
                const float* temperatures, const int64_t* top_ks, const float* top_ps,
                const float* min_ps, int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset,
-               int64_t* out_ids, nvx_stream_t stream);
+               int64_t* out_ids, void* ws, int64_t ws_bytes, nvx_stream_t stream);
 int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_stride,
                       const float* temperatures, const int64_t* top_ks, const float* top_ps,
                       const float* min_ps, int64_t batch, int64_t vocab, float* probs_out,

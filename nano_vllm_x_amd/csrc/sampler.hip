@@ -1,8 +1,13 @@
 // Sampler for gfx950: temperature, top-k, top-p, min-p, categorical draw -- without sorting the vocabulary.
 //
-// One 1024-thread workgroup per row; the row (<= 608 KB) is re-read from L2 on every pass.
 //   * rows with no active filter (top_k >= vocab, top_p >= 1, min_p <= 0): ONE pass,
-//     token = argmax_i(logit_i / T + Gumbel_i): an exact categorical draw from softmax(logits / T);
+//     token = argmax_i(logit_i / T + Gumbel_i): an exact categorical draw from softmax(logits / T).
+//     The pass is bound by the Philox and log arithmetic of one compute unit, so with a caller
+//     workspace a row is cut into up to 16 slices, one 1024-thread workgroup each; every slice
+//     leaves its (score, token) winner as one 64-bit key and a second small kernel takes the
+//     maximum per row;
+//   * filtered rows: one 1024-thread workgroup per row; the row (<= 608 KB) is re-read from L2 on
+//     every pass;
 //   * otherwise the reference's sort is replaced by radix selection on the order-preserving integer
 //     image of the fp32 scores (4 passes of 8 bits, 256-bin LDS histograms):
 //       top-k  -> the k-th largest score (counts);
@@ -14,6 +19,7 @@
 #include "nvx_dev.h"
 
 #define SMP_THREADS 1024
+#define SMP_MAX_SPLIT 16
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
@@ -38,6 +44,11 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t r) {
 __device__ __forceinline__ uint32_t order_key(float x) {
     const uint32_t u = __float_as_uint(x);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// (score, token) as one 64-bit key: larger score wins, then the lower token id
+__device__ __forceinline__ unsigned long long pack_winner(float v, int idx) {
+    return ((unsigned long long)order_key(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)idx);
 }
 
 template <bool F32>
@@ -117,9 +128,9 @@ template <bool F32, bool PROBS>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(
     const void* __restrict__ logits, int64_t row_stride, const float* __restrict__ temps, const int64_t* __restrict__ top_ks,
     const float* __restrict__ top_ps, const float* __restrict__ min_ps, int vocab, uint64_t seed, uint64_t offset,
-    int64_t* __restrict__ out_ids, float* __restrict__ probs_out) {
+    int64_t* __restrict__ out_ids, float* __restrict__ probs_out, unsigned long long* __restrict__ winners, int n_split) {
     __shared__ BlockScratch sc;
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
     const void* lrow = F32 ? (const void*)((const float*)logits + row * row_stride)
                            : (const void*)((const uint16_t*)logits + row * row_stride);
     const float T = temps[row];
@@ -130,22 +141,32 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
 
     if (!filtered && !PROBS) {
-        // single pass: Gumbel-max.  Four tokens share one Philox block.
+        // single pass: Gumbel-max over this workgroup's slice.  Four tokens share one Philox block.
+        const int per = ((vocab + n_split - 1) / n_split + 3) & ~3;
+        const int lo = slice * per, hi = min(vocab, lo + per);
+        const float inv_t = 1.0f / T;
         float best = -INFINITY; int besti = 0x7fffffff;
-        for (int base = tid * 4; base < vocab; base += SMP_THREADS * 4) {
+        for (int base = lo + tid * 4; base < hi; base += SMP_THREADS * 4) {
             const uint4 r = philox4x32_10(make_uint4((uint32_t)(base >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)), key);
             const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = base + j;
-                if (i < vocab) {
-                    const float v = load_logit<F32>(lrow, i) / T + gumbel_from_bits(rr[j]);
+                if (i < hi) {
+                    const float v = load_logit<F32>(lrow, i) * inv_t + gumbel_from_bits(rr[j]);
                     if (v > best) { best = v; besti = i; }
                 }
             }
         }
         block_argmax(best, besti, sc);
-        if (tid == 0) out_ids[row] = besti == 0x7fffffff ? 0 : besti;
+        if (tid == 0) {
+            if (winners) winners[(int64_t)row * n_split + slice] = besti == 0x7fffffff ? 0ull : pack_winner(best, besti);
+            else out_ids[row] = besti == 0x7fffffff ? 0 : besti;
+        }
+        return;
+    }
+    if (slice > 0) {   // a filtered row is handled whole by its first workgroup
+        if (tid == 0) winners[(int64_t)row * n_split + slice] = 0ull;
         return;
     }
 
@@ -322,7 +343,20 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(
         }
     }
     block_argmax(best, besti, sc);
-    if (tid == 0) out_ids[row] = besti == 0x7fffffff ? 0 : besti;
+    if (tid == 0) {
+        if (winners) winners[(int64_t)row * n_split] = besti == 0x7fffffff ? 0ull : pack_winner(best, besti);
+        else out_ids[row] = besti == 0x7fffffff ? 0 : besti;
+    }
+}
+
+// Per row: the best of the slices' winners.
+__global__ __launch_bounds__(256) void sample_finish_kernel(const unsigned long long* __restrict__ winners, int n_split, int batch,
+                                                            int64_t* __restrict__ out_ids) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= batch) return;
+    unsigned long long w = 0;
+    for (int s = 0; s < n_split; ++s) { const unsigned long long o = winners[(int64_t)row * n_split + s]; w = o > w ? o : w; }
+    out_ids[row] = w == 0 ? 0 : (int64_t)(0xffffffffu - (uint32_t)(w & 0xffffffffull));
 }
 
 static int sampler_check(const void* logits, int64_t stride, const float* t, const int64_t* k, const float* p, const float* mp,
@@ -333,21 +367,38 @@ static int sampler_check(const void* logits, int64_t stride, const float* t, con
     return NVX_OK;
 }
 
+extern "C" int64_t nvx_sample_ws_bytes(int64_t max_batch) { return max_batch * SMP_MAX_SPLIT * 8; }
+
 extern "C" int nvx_sample(const void* logits, int logits_is_f32, int64_t logits_row_stride, const float* temperatures,
                           const int64_t* top_ks, const float* top_ps, const float* min_ps, int64_t batch, int64_t vocab,
-                          uint64_t seed, uint64_t offset, int64_t* out_ids, nvx_stream_t stream) {
+                          uint64_t seed, uint64_t offset, int64_t* out_ids, void* ws, int64_t ws_bytes, nvx_stream_t stream) {
     int rc = sampler_check(logits, logits_row_stride, temperatures, top_ks, top_ps, min_ps, batch, vocab, "nvx_sample");
     if (rc) return rc;
     if (batch == 0) return NVX_OK;
     NVX_REQUIRE(out_ids, NVX_EINVAL, "nvx_sample: null pointer");
+    NVX_REQUIRE(batch <= 65535, NVX_EUNSUPPORTED, "nvx_sample: more than 65535 rows");
+    // slices per row: enough workgroups for two per compute unit, none without a workspace
+    int n_split = 1;
+    if (ws) {
+        NVX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0, NVX_EINVAL, "nvx_sample: workspace must be 8-byte aligned");
+        n_split = (int)(512 / batch);
+        n_split = n_split < 1 ? 1 : (n_split > SMP_MAX_SPLIT ? SMP_MAX_SPLIT : n_split);
+        NVX_REQUIRE(ws_bytes >= batch * n_split * 8, NVX_ENOSPACE, "nvx_sample: workspace too small (%lld < %lld bytes)",
+                    (long long)ws_bytes, (long long)(batch * n_split * 8));
+    }
+    unsigned long long* winners = (unsigned long long*)ws;
     hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n_split, (unsigned)batch);
     if (logits_is_f32)
-        hipLaunchKernelGGL((sample_kernel<true, false>), dim3((unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, (float*)nullptr);
+        hipLaunchKernelGGL((sample_kernel<true, false>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, (float*)nullptr, winners, n_split);
     else
-        hipLaunchKernelGGL((sample_kernel<false, false>), dim3((unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, (float*)nullptr);
-    return nvx_check_launch("nvx_sample");
+        hipLaunchKernelGGL((sample_kernel<false, false>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, (float*)nullptr, winners, n_split);
+    rc = nvx_check_launch("nvx_sample");
+    if (rc || !ws) return rc;
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, winners, n_split, (int)batch, out_ids);
+    return nvx_check_launch("nvx_sample(finish)");
 }
 
 extern "C" int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_stride, const float* temperatures,
@@ -357,12 +408,15 @@ extern "C" int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t 
     if (rc) return rc;
     if (batch == 0) return NVX_OK;
     NVX_REQUIRE(probs_out, NVX_EINVAL, "nvx_sampler_probs: null pointer");
+    NVX_REQUIRE(batch <= 65535, NVX_EUNSUPPORTED, "nvx_sampler_probs: more than 65535 rows");
     hipStream_t st = (hipStream_t)stream;
     if (logits_is_f32)
-        hipLaunchKernelGGL((sample_kernel<true, true>), dim3((unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, 0ull, 0ull, (int64_t*)nullptr, probs_out);
+        hipLaunchKernelGGL((sample_kernel<true, true>), dim3(1, (unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, 0ull, 0ull, (int64_t*)nullptr, probs_out,
+                           (unsigned long long*)nullptr, 1);
     else
-        hipLaunchKernelGGL((sample_kernel<false, true>), dim3((unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, 0ull, 0ull, (int64_t*)nullptr, probs_out);
+        hipLaunchKernelGGL((sample_kernel<false, true>), dim3(1, (unsigned)batch), dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, 0ull, 0ull, (int64_t*)nullptr, probs_out,
+                           (unsigned long long*)nullptr, 1);
     return nvx_check_launch("nvx_sampler_probs");
 }

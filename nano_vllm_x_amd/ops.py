@@ -232,9 +232,27 @@ def _sampler_args(logits, temperatures, top_ks, top_ps, min_ps):
     return b, v
 
 
-def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int, offset: int, out=None):
+_SAMPLE_WS: dict = {}   # device -> int64 workspace (slices' winners), grown on demand outside graph capture
+
+
+def sample_workspace(batch: int, device) -> torch.Tensor:
+    """Workspace that lets nvx_sample cut rows into slices.  Allocate it before capturing a graph that
+    samples: the captured launch keeps the pointer."""
+    lib = _lib.load()
+    need = int(lib.nvx_sample_ws_bytes(batch)) // 8
+    key = torch.device(device)
+    ws = _SAMPLE_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, int(lib.nvx_sample_ws_bytes(256)) // 8), dtype=torch.int64, device=device)
+        _SAMPLE_WS[key] = ws
+    return ws
+
+
+def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int, offset: int, out=None, ws=None):
     """Sampler.forward (sampler.py:39-55): one token id per row, Philox(seed, offset) Gumbel-max draw."""
     b, v = _sampler_args(logits, temperatures, top_ks, top_ps, min_ps)
+    if ws is None:
+        ws = sample_workspace(b, logits.device)
     if out is None:
         out = torch.empty((b,), dtype=torch.int64, device=logits.device)
     else:
@@ -242,7 +260,7 @@ def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int, offset: int,
     lib = _lib.load()
     _lib.check(lib.nvx_sample(_ptr(logits), int(logits.dtype == torch.float32), logits.stride(0), _ptr(temperatures),
                               _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), b, v, seed & (2**64 - 1), offset & (2**64 - 1),
-                              _ptr(out), _stream()), "nvx_sample")
+                              _ptr(out), _ptr(ws), ws.numel() * 8, _stream()), "nvx_sample")
     return out
 
 

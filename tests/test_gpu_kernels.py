@@ -399,3 +399,42 @@ def test_torch_ops_namespace_calls_the_same_kernels(ops):
     assert torch.equal(y0, y1) and torch.equal(r0, r1)
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.nvx.silu_mul(x.cpu())   # no CPU kernel is registered
+
+
+def test_sampler_sliced_rows_draw_the_same_tokens(ops):
+    """With a workspace, unfiltered rows are cut into slices over several workgroups; the draw must be the
+    token the one-workgroup path draws, and filtered rows in the same batch must be unaffected."""
+    from nano_vllm_x_amd import _lib
+
+    gen = torch.Generator().manual_seed(12)
+    v, b = 151936, 7
+    logits = (torch.randn(b, v, generator=gen) * 2).to(torch.bfloat16).to(DEV)
+    t = torch.full((b,), 0.6, device=DEV)
+    k = torch.full((b,), v, dtype=torch.int64, device=DEV)
+    p = torch.ones(b, device=DEV)
+    mp = torch.zeros(b, device=DEV)
+    k[2], p[4] = 50, 0.9          # two filtered rows among unfiltered ones
+    lib = _lib.load()
+
+    def run(ws):
+        out = torch.full((b,), -1, dtype=torch.int64, device=DEV)
+        rc = lib.nvx_sample(logits.data_ptr(), 0, logits.stride(0), t.data_ptr(), k.data_ptr(), p.data_ptr(), mp.data_ptr(), b, v,
+                            77, 5, out.data_ptr(), ws.data_ptr() if ws is not None else None, ws.numel() * 8 if ws is not None else 0,
+                            torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.nvx_last_error()
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    ws = torch.empty(int(lib.nvx_sample_ws_bytes(b)) // 8, dtype=torch.int64, device=DEV)
+    whole, sliced = run(None), run(ws)
+    assert torch.equal(whole, sliced)
+    assert ((whole >= 0) & (whole < v)).all()
+    # the top-k row drew one of its 50 best tokens
+    top50 = torch.topk(logits[2].float(), 50).indices.cpu()
+    assert whole[2] in top50
+    # a workspace that is too small is refused, not overrun
+    small = torch.empty(4, dtype=torch.int64, device=DEV)
+    rc = lib.nvx_sample(logits.data_ptr(), 0, logits.stride(0), t.data_ptr(), k.data_ptr(), p.data_ptr(), mp.data_ptr(), b, v, 77, 5,
+                        torch.empty(b, dtype=torch.int64, device=DEV).data_ptr(), small.data_ptr(), small.numel() * 8,
+                        torch.cuda.current_stream().cuda_stream)
+    assert rc == -4
