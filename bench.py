@@ -156,7 +156,9 @@ def _pmc_traffic(kernel: str):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(path):
         with open(path) as f:
-            return json.load(f).get(kernel)
+            d = json.load(f)
+        if kernel in d:   # the main kernel and the merge kernel that completes it
+            return int(d[kernel]) + int(d.get("decode_merge_kernel", 0))
     return None
 
 
