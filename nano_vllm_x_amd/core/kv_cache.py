@@ -253,6 +253,9 @@ class KVCacheManager:
         self.kv_cache_allocator = KVCacheAllocator(size)
         self.radix_tree = RadixTree(self.kv_cache_allocator)
         self.unfinished_sequences: dict = {}   # seq_id -> (prefix_len, last_node)
+        self.adopted: dict = {}                # prefix-reuse mode: seq_id -> (shared_len, tree node held)
+        self.prefix_hit_tokens = 0             # prompt tokens whose KV rows came from the tree
+        self.prefix_query_tokens = 0           # prompt tokens looked up
 
     def alloc_slots(self, num_slots: int):
         got = self.kv_cache_allocator.alloc(num_slots)
@@ -285,3 +288,51 @@ class KVCacheManager:
             self.unfinished_sequences.pop(seq.seq_id, None)
             seq.kv_indices.clear()   # the tree owns them now
             seq.cached_kv_len = 0
+
+    # -- admission-time prefix reuse (not in the reference: its tree is never consulted at admission) --
+    def adopt_cached_prefix(self, seq: Sequence) -> int:
+        """Point the head of `seq.kv_indices` at the slots of the longest cached prefix of its tokens and
+        pin that path in the tree.  At least one token is left to compute (its logits are needed).
+        Returns the number of tokens adopted."""
+        assert not seq.kv_indices and seq.seq_id not in self.adopted
+        n = len(seq.token_ids)
+        self.prefix_query_tokens += n
+        if n < 2:
+            return 0
+        slots, node = self.radix_tree.match_prefix(seq.token_ids[:-1])
+        if not slots:
+            return 0
+        self.radix_tree.inc_ref(node)
+        self.adopted[seq.seq_id] = (len(slots), node)
+        seq.kv_indices.extend(slots)
+        seq.cached_kv_len = len(slots)
+        self.prefix_hit_tokens += len(slots)
+        return len(slots)
+
+    def release_sequence(self, seq: Sequence):
+        """Give back what a sequence owns (preemption, failed admission): its private slots go to the
+        allocator, the adopted prefix stays in the tree and is unpinned."""
+        shared, node = self.adopted.pop(seq.seq_id, (0, None))
+        if node is not None:
+            self.radix_tree.dec_ref(node)
+        self.kv_cache_allocator.free(seq.kv_indices[shared:])
+        seq.kv_indices.clear()
+        seq.cached_kv_len = 0
+
+    def cache_sequence_shared(self, seq: Sequence):
+        """Prefix-reuse counterpart of cache_sequence: only tokens that have a KV row are keyed (so
+        every node has as many slots as tokens), slots that duplicate rows the tree already holds are
+        freed instead of leaked, and the adopted prefix is unpinned."""
+        tree = self.radix_tree
+        shared, node = self.adopted.pop(seq.seq_id, (0, None))
+        n = len(seq.kv_indices)
+        if n:
+            matched, _ = tree.insert(seq.token_ids[:n], seq.kv_indices)
+            # [0, shared) are the tree's own slots; [shared, matched) were computed here but another
+            # sequence cached the same tokens first; [matched, n) now belong to the new leaf
+            if matched > shared:
+                self.kv_cache_allocator.free(seq.kv_indices[shared:matched])
+        if node is not None:
+            tree.dec_ref(node)
+        seq.kv_indices.clear()
+        seq.cached_kv_len = 0

@@ -15,6 +15,12 @@ Three departures, all where the reference cannot complete:
     sequences finish, and the error is raised only when nothing is running.
   * Queue membership is by object identity and O(1) per test, instead of field-wise dataclass
     comparison of whole token lists (scheduler.py:146,148,184).
+
+One addition, off by default: `prefix_reuse=True` consults the radix tree when a sequence is admitted
+(the reference builds the tree but never reads it at admission, so none of its requests reuses a
+cached prefix).  The matched prefix's slots become the head of the sequence's block table, the prefill
+computes only the rest, and the slot accounting at finish/preemption distinguishes shared from owned
+slots.  With the flag off every decision is the reference's.
 """
 from __future__ import annotations
 
@@ -26,9 +32,10 @@ from .kv_cache import KVCacheManager
 
 
 class Scheduler:
-    def __init__(self, kv_cache_size: int, max_bs: int = 32):
+    def __init__(self, kv_cache_size: int, max_bs: int = 32, prefix_reuse: bool = False):
         self.kv_cache_size = kv_cache_size
         self.max_bs = max_bs
+        self.prefix_reuse = prefix_reuse
         self.sequences: dict = {}
         self.waiting: Deque[Sequence] = deque()
         self.running: Deque[Sequence] = deque()
@@ -55,6 +62,9 @@ class Scheduler:
             seq.kv_indices.extend(self.kv_manager.alloc_slots(missing))
 
     def free_kv_slots(self, seq: Sequence):
+        if self.prefix_reuse:
+            self.kv_manager.release_sequence(seq)
+            return
         if seq.kv_indices:
             self.kv_manager.free_slots(seq.kv_indices)
             seq.kv_indices.clear()
@@ -80,8 +90,12 @@ class Scheduler:
         while self.waiting and len(picked) < self.max_bs:
             seq = self.waiting.popleft()
             try:
+                if self.prefix_reuse and not seq.kv_indices:
+                    self.kv_manager.adopt_cached_prefix(seq)
                 self.alloc_kv_slots(seq)
             except RuntimeError:
+                if self.prefix_reuse:
+                    self.kv_manager.release_sequence(seq)
                 self.waiting.appendleft(seq)
                 if not picked and not self.running:
                     raise
@@ -156,7 +170,10 @@ class Scheduler:
             self.running.remove(seq)
             self.scheduled.discard(seq.seq_id)
         seq.status = SequenceStatus.FINISHED
-        self.kv_manager.cache_sequence(seq)
+        if self.prefix_reuse:
+            self.kv_manager.cache_sequence_shared(seq)
+        else:
+            self.kv_manager.cache_sequence(seq)
         self.sequences.pop(seq.seq_id, None)
         if self.on_release:
             self.on_release(seq)

@@ -120,3 +120,43 @@ def test_llm_generate_api():
     assert [len(r) for r in res] == [5, 3, 7]
     assert all(r[-1].is_finished and r[-1].finish_reason.name == "LENGTH" for r in res)
     assert res[0][-1].num_prompt_tokens == 4 and res[0][-1].num_generated_tokens == 5
+
+
+def test_prefix_reuse_generates_the_same_tokens_with_fewer_prefill_rows():
+    """Requests sharing a cached system prompt: with Scheduler(prefix_reuse=True) the shared rows are
+    read from the pool instead of recomputed.  Greedy streams must equal those of the reference-faithful
+    path (flag off); the prefill must have computed fewer rows."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    rng = np.random.default_rng(1)
+    system = rng.integers(0, 256, size=24).tolist()
+    requests = [("warm", system + [5], 3)] + [(f"r{i}", system + rng.integers(0, 256, size=int(rng.integers(2, 9))).tolist(),
+                                               int(rng.integers(3, 8))) for i in range(6)]
+    results = {}
+    for reuse in (False, True):
+        runner, _ = _tiny_runner(enforce_eager=False, max_bs=4, kv_slots=600, context_len=64)
+        core = EngineCore(kv_cache_size=600, max_bs=4, context_len=64, prefix_reuse=reuse)
+        core.scheduler.on_release = runner.release_sequence
+        got, prefill_rows = {}, 0
+
+        def run_all():
+            nonlocal prefill_rows
+            while core.has_unfinished_sequences():
+                batch = core.scheduler.schedule()
+                if batch.forward_mode == ForwardMode.PREFILL:
+                    prefill_rows += sum(len(s.token_ids) - s.cached_kv_len for s in batch.seqs)
+                toks = runner.execute_model(batch)
+                for o in core.update_from_output(batch, toks):
+                    got.setdefault(o.seq_id, []).append(o.new_token_id)
+
+        sid, prompt, n = requests[0]
+        core.add_sequence(sid, list(prompt), SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=n))
+        run_all()                       # the warm-up request finishes and its rows enter the tree
+        for sid, prompt, n in requests[1:]:
+            core.add_sequence(sid, list(prompt), SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=n))
+        run_all()
+        results[reuse] = (got, prefill_rows, core.scheduler.kv_manager.prefix_hit_tokens)
+    assert results[True][0] == results[False][0]
+    assert results[False][2] == 0 and results[True][2] == 6 * 24
+    assert results[True][1] == results[False][1] - 6 * 24
