@@ -248,7 +248,7 @@ def main():
                    "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph"},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
         "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
-        "engine_steps": {k: stats1[k] - stats0[k] for k in stats1}, "init_s": round(init_s, 1),
+        "engine_steps": {k: round(stats1[k] - stats0.get(k, 0), 3) for k in stats1}, "init_s": round(init_s, 1),
         "vs_baseline_note": "reference README: 9032.37 tok/s on 1x A100 40GB (other hardware)",
     }
 

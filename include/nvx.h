@@ -92,6 +92,31 @@ int nvx_qknorm_rope_store(const void* qkv, int64_t qkv_row_stride, const int64_t
 int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Linear layer of a decode step: y = x * w^T for m <= 256 activation rows.  Stands where the
+ * reference's parallel linears call F.linear on decode batches (nanovllmx/layers/linear.py:292,
+ * 467-470 under models/qwen3.py:121,135,161-163), fused with the elementwise op that follows it.
+ * x: (m, k) bf16 rows x_row_stride apart; w: (n, k) bf16 row-major (an nn.Linear weight).
+ * mode 0: y bf16 (m, n).
+ * mode 1: w = [gate rows; up rows] (n/2 each); y bf16 (m, n/2) = SiluAndMul of the bf16-rounded
+ *         projection (nanovllmx/layers/activation.py:15-18).
+ * mode 2: K is cut into k_splits slices handled by different workgroups; y fp32 (k_splits, m, n)
+ *         partial products, to be summed by nvx_rmsnorm_splitk.  nvx_linear_decode_splits(n, k)
+ *         proposes k_splits.
+ * fp32 accumulation on MFMA; k / k_splits must be 512, 768 or 1024 (nvx_linear_decode_splits
+ * returns 0 when no split of k gives one of them: use a library GEMM then); output width a
+ * multiple of 16. */
+int nvx_linear_decode_splits(int64_t n, int64_t k);
+int nvx_linear_decode(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m,
+                      int64_t n, int64_t k, int mode, int k_splits, nvx_stream_t stream);
+
+/* RMSNorm.forward (nanovllmx/layers/layernorm.py:17-36) on the output of a K-split projection:
+ * x = bf16(sum of the k_splits fp32 partials (n_splits, rows, hidden)), then as nvx_rmsnorm with a
+ * bf16 weight.  residual / residual_out as in nvx_rmsnorm. */
+int nvx_rmsnorm_splitk(const float* partials, int n_splits, const void* residual, const void* weight,
+                       void* y, void* residual_out, int64_t rows, int64_t hidden, float eps,
+                       nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Paged attention, decode: one query token per sequence.  Replaces
  * BatchDecodeWithPagedKVCacheWrapper.plan/run as called from
  * nanovllmx/layers/attention.py:120-132,197-207,277-288 (plan) and :365-369 (run),

@@ -32,6 +32,9 @@ SIGNATURES = {
     "nvx_prefill_plan": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp]),
     "nvx_paged_prefill": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
                                    _c_i32, _c_i32, _c_f32, _c_vp]),
+    "nvx_linear_decode_splits": (_c_i32, [_c_i64, _c_i64]),
+    "nvx_linear_decode": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_vp]),
+    "nvx_rmsnorm_splitk": (_c_i32, [_c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_f32, _c_vp]),
     "nvx_sample_ws_bytes": (_c_i64, [_c_i64]),
     "nvx_sample": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_vp, _c_i64, _c_vp]),
     "nvx_sampler_probs": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),

@@ -13,6 +13,8 @@ What differs, by design, on MI355X:
 """
 from __future__ import annotations
 
+import time
+
 import gc
 from typing import Optional
 
@@ -53,7 +55,7 @@ class ModelRunner:
         self._config_override = config
         self.graph: Optional[HIPGraph] = None
         self.block_table: Optional[BlockTable] = None
-        self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0}
+        self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
 
     # -- set-up -----------------------------------------------------------------------------------
     def load_model(self, state_dict_iter=None):
@@ -156,6 +158,14 @@ class ModelRunner:
     def execute_model(self, batch: ForwardBatch) -> list:
         if batch.num_seqs == 0:
             return []
+        t0 = time.perf_counter()
+        try:
+            return self._execute_model(batch)
+        finally:   # the step ends with a stream synchronisation, so host wall time is step time
+            key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
+            self.stats[key] = self.stats.get(key, 0.0) + (time.perf_counter() - t0)
+
+    def _execute_model(self, batch: ForwardBatch) -> list:
         logits = self.compute_logits(batch)
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs

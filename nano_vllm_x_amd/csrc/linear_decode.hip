@@ -1,0 +1,170 @@
+// Skinny linear layer for decode steps on gfx950: Y[M, N] = X[M, K] * W[N, K]^T with M <= 256 rows
+// (one per running sequence), bf16 in, fp32 accumulate.
+//
+// At these sizes the layer is a stream of the weight matrix (each byte used once per step) with the
+// whole activation matrix re-read from L2 by every workgroup, so the design is about bytes in flight
+// and a short dependent chain, not FLOPs:
+//   * a workgroup owns 16 rows of W over one slice of K (grid = N/16 x k_splits, so that even a
+//     1024-row projection puts >= 256 workgroups on the chip); its 512 threads pull that slice with
+//     16-byte loads issued all at once and park it in LDS in MFMA operand order (XOR-swizzled so that
+//     both the row-major writes and the fragment reads are bank-conflict free);
+//   * each of the 8 waves owns every eighth 16-row tile of X: B fragments come straight from global memory
+//     (L2-resident activations) in double-buffered groups of 8 k-steps, A fragments from LDS,
+//     v_mfma_f32_16x16x32_bf16 accumulates; no cross-wave reduction is needed;
+//   * epilogues: bf16 store; SiLU(gate) * up for a fused gate/up projection (the workgroup owns 16
+//     gate rows and the 16 matching up rows); fp32 partials when K is split across workgroups, which
+//     the RMSNorm kernel that follows sums (nvx_rmsnorm_splitk).
+#include "nvx_dev.h"
+
+#define LIN_THREADS 512
+#define LIN_WAVES 8
+
+__device__ __forceinline__ nvx_f32x4 mfma16(nvx_u32x4 a, nvx_u32x4 b, nvx_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nvx_bf16x8, a), __builtin_bit_cast(nvx_bf16x8, b), c, 0, 0, 0);
+}
+
+// LDS slot (16 bytes each) of the A fragment piece: k-step j, lane quad q (k offset 8q), W row r.
+__device__ __forceinline__ int lin_slot(int j, int q, int r) { return j * 64 + q * 16 + (r ^ ((q << 2) | (j & 3))); }
+
+// MODE 0: y bf16 (M, N).  MODE 1: w rows [0, N/2) are gate rows, [N/2, N) up rows; y bf16 (M, N/2) =
+// bf16(bf16(silu(gate)) * up) on the bf16-rounded projections, as the unfused ops compute it.
+// MODE 2: fp32 partials (k_splits, M, N).
+// KC = the K slice of one workgroup (compile time, so that every loop below is straight-line code:
+// with per-element bounds checks the compiler serialises each load behind a full wait).
+template <int MODE, int KC>
+__global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
+    const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* __restrict__ w, void* __restrict__ y, int m_rows, int n_rows,
+    int k_total) {
+    constexpr int HALVES = MODE == 1 ? 2 : 1;
+    constexpr int STEPS = KC / 32;               // MFMA k-steps per tile
+    constexpr int GROUP = 8;                     // k-steps per prefetch group
+    constexpr int GPT = STEPS / GROUP;           // groups per tile
+    constexpr int PIECES_ROW = KC / 8;           // 16-byte pieces per W row
+    constexpr int PIECES_HALF = 16 * PIECES_ROW;
+    constexpr int WLOADS = HALVES * PIECES_HALF / LIN_THREADS;   // pieces per thread, all in flight at once
+    static_assert(KC % 256 == 0, "K slice must be a multiple of 256");
+    __shared__ nvx_u32x4 lds[HALVES * STEPS * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int quad = lane >> 4, l16 = lane & 15;
+    const int n_out = MODE == 1 ? n_rows / 2 : n_rows;
+    const int n0 = blockIdx.x * 16;
+    const int k0 = blockIdx.y * KC;
+
+    // ---- this wave's work: (tile, group of 8 k-steps) items; the first item's X loads go in flight before W
+    const int tiles = (m_rows + 15) / 16;
+    const int my_tiles = tiles > wave ? (tiles - wave + LIN_WAVES - 1) / LIN_WAVES : 0;
+    const int n_items = my_tiles * GPT;
+    nvx_u32x4 b_even[GROUP], b_odd[GROUP];
+    auto load_b = [&](nvx_u32x4 (&dst)[GROUP], int item) {
+        const int tile = wave + LIN_WAVES * (item / GPT), group = item % GPT;
+        int row = tile * 16 + l16;
+        row = row < m_rows ? row : m_rows - 1;
+        const uint16_t* p = x + (int64_t)row * x_stride + k0 + group * (GROUP * 32) + quad * 8;
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) dst[i] = *reinterpret_cast<const nvx_u32x4*>(p + i * 32);
+    };
+    if (n_items > 0) load_b(b_even, 0);
+
+    // ---- W slice -> LDS, parked in operand order ---------------------------------------------------
+    {
+        nvx_u32x4 v[WLOADS];
+#pragma unroll
+        for (int u = 0; u < WLOADS; ++u) {
+            const int p = u * LIN_THREADS + tid;
+            const int h = p / PIECES_HALF, ph = p % PIECES_HALF;
+            const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
+            v[u] = *reinterpret_cast<const nvx_u32x4*>(w + (int64_t)(n0 + h * n_out + r) * k_total + k0 + kp * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < WLOADS; ++u) {
+            const int p = u * LIN_THREADS + tid;
+            const int h = p / PIECES_HALF, ph = p % PIECES_HALF;
+            const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
+            lds[h * STEPS * 64 + lin_slot(kp >> 2, kp & 3, r)] = v[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- tiles of X ------------------------------------------------------------------------------
+    nvx_f32x4 acc[HALVES];
+    auto compute = [&](const nvx_u32x4 (&bfrag)[GROUP], int item) {
+        const int tile = wave + LIN_WAVES * (item / GPT), g = item % GPT;
+        if (g == 0) {
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) acc[h] = nvx_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h)
+                acc[h] = mfma16(lds[h * STEPS * 64 + lin_slot(g * GROUP + i, quad, l16)], bfrag[i], acc[h]);
+        }
+        if (g != GPT - 1) return;
+        // C layout: this lane holds X row (tile*16 + l16), W rows n0 + 4*quad + 0..3
+        const int row = tile * 16 + l16;
+        if (row >= m_rows) return;
+        const int col = n0 + quad * 4;
+        if (MODE == 0) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_rows + col;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[0][2], acc[0][3]));
+        } else if (MODE == 1) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gate = round_bf16(acc[0][r]), up = round_bf16(acc[HALVES - 1][r]);
+                const float sg = round_bf16(gate / (1.0f + __expf(-gate)));
+                o[r] = sg * up;
+            }
+            uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_out + col;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        } else {
+            float* dst = reinterpret_cast<float*>(y) + ((int64_t)blockIdx.y * m_rows + row) * n_rows + col;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        }
+    };
+    // the next item's loads go in flight before the current item is multiplied
+    for (int item = 0; item < n_items; item += 2) {
+        if (item + 1 < n_items) load_b(b_odd, item + 1);
+        compute(b_even, item);
+        if (item + 1 >= n_items) break;
+        if (item + 2 < n_items) load_b(b_even, item + 2);
+        compute(b_odd, item + 1);
+    }
+}
+
+static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
+
+extern "C" int nvx_linear_decode_splits(int64_t n, int64_t k) {
+    // smallest split whose K slice is one of the built sizes, preferring >= 256 workgroups; 0 = none
+    int best = 0;
+    for (int s = 1; s <= 16; ++s) {
+        if (k % s || !lin_chunk_ok(k / s)) continue;
+        best = s;
+        if ((n / 16) * s >= 256) break;
+    }
+    return best;
+}
+
+extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m, int64_t n, int64_t k,
+                                 int mode, int k_splits, nvx_stream_t stream) {
+    NVX_REQUIRE(x && w && y, NVX_EINVAL, "nvx_linear_decode: null pointer");
+    NVX_REQUIRE(m > 0 && m <= 256, NVX_EUNSUPPORTED, "nvx_linear_decode: 1..256 rows (got %lld); larger batches are a library GEMM", (long long)m);
+    NVX_REQUIRE(mode >= 0 && mode <= 2, NVX_EINVAL, "nvx_linear_decode: mode must be 0, 1 or 2");
+    NVX_REQUIRE(k_splits >= 1 && (mode == 2 || k_splits == 1), NVX_EINVAL, "nvx_linear_decode: only mode 2 (fp32 partials) may split K");
+    NVX_REQUIRE(k > 0 && k % k_splits == 0 && lin_chunk_ok(k / k_splits), NVX_EUNSUPPORTED,
+                "nvx_linear_decode: K / k_splits must be 512, 768 or 1024 (got %lld / %d)", (long long)k, k_splits);
+    const int64_t n_out = mode == 1 ? n / 2 : n;
+    NVX_REQUIRE(n > 0 && n_out % 16 == 0 && (mode != 1 || n % 2 == 0), NVX_EUNSUPPORTED, "nvx_linear_decode: output width must be a multiple of 16");
+    NVX_REQUIRE(x_row_stride >= k && x_row_stride % 8 == 0, NVX_EINVAL, "nvx_linear_decode: bad x row stride");
+    NVX_REQUIRE(nvx_aligned16(x) && nvx_aligned16(w) && nvx_aligned16(y), NVX_EINVAL, "nvx_linear_decode: pointers must be 16-byte aligned");
+    const int kc = (int)(k / k_splits);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(n_out / 16), (unsigned)k_splits);
+#define NVX_LIN(MODE, KC) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
+                                             x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
+#define NVX_LIN_KC(MODE) do { if (kc == 512) NVX_LIN(MODE, 512); else if (kc == 768) NVX_LIN(MODE, 768); else NVX_LIN(MODE, 1024); } while (0)
+    if (mode == 0) NVX_LIN_KC(0); else if (mode == 1) NVX_LIN_KC(1); else NVX_LIN_KC(2);
+#undef NVX_LIN_KC
+#undef NVX_LIN
+    return nvx_check_launch("nvx_linear_decode");
+}

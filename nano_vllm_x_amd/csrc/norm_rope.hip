@@ -107,6 +107,101 @@ extern "C" int nvx_rmsnorm(const void* x, int64_t x_row_stride, const void* resi
     return nvx_check_launch("nvx_rmsnorm");
 }
 
+// RMSNorm whose input is the set of fp32 partial products a K-split linear layer left behind
+// (nvx_linear_decode mode 2): x = bf16(sum over splits), i.e. what the unsplit projection would have
+// stored, then the same arithmetic as rmsnorm_kernel.  One wave per row.
+template <int ITERS, bool HAS_RES>
+__global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
+    const float* __restrict__ partials, int n_splits, const uint16_t* residual, const uint16_t* __restrict__ weight,
+    uint16_t* y, uint16_t* residual_out, int rows, int hidden, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t split_stride = (int64_t)rows * hidden;
+    float v[ITERS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int col = it * 512 + lane * 8;
+        if (col < hidden) {
+            const float* p = partials + (int64_t)row * hidden + col;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < n_splits; ++s) {
+                const float4 lo = *reinterpret_cast<const float4*>(p + s * split_stride);
+                const float4 hi = *reinterpret_cast<const float4*>(p + s * split_stride + 4);
+                a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
+                a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+            }
+            if (HAS_RES) {
+                const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)row * hidden + col);
+                const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = round_bf16(a[2 * j]) + bf16lo_to_f32(rw[j]);
+                    const float hi = round_bf16(a[2 * j + 1]) + bf16hi_to_f32(rw[j]);
+                    v[it][2 * j] = lo;
+                    v[it][2 * j + 1] = hi;
+                    ow[j] = pack_bf16x2(lo, hi);
+                }
+                *reinterpret_cast<uint4*>(residual_out + (int64_t)row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[it][j] = round_bf16(a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int col = it * 512 + lane * 8;
+        if (col < hidden) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(weight + col);
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ow[j] = pack_bf16x2((v[it][2 * j] * inv) * bf16lo_to_f32(ww[j]), (v[it][2 * j + 1] * inv) * bf16hi_to_f32(ww[j]));
+            *reinterpret_cast<uint4*>(y + (int64_t)row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+template <int ITERS>
+static void launch_rmsnorm_splitk(const float* p, int s, const void* res, const void* w, void* y, void* ro, int rows, int hidden,
+                                  float eps, hipStream_t st) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (res) hipLaunchKernelGGL((rmsnorm_splitk_kernel<ITERS, true>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+                                (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
+    else hipLaunchKernelGGL((rmsnorm_splitk_kernel<ITERS, false>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+                            (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
+}
+
+extern "C" int nvx_rmsnorm_splitk(const float* partials, int n_splits, const void* residual, const void* weight, void* y,
+                                  void* residual_out, int64_t rows, int64_t hidden, float eps, nvx_stream_t stream) {
+    NVX_REQUIRE(rows >= 0 && rows <= 65536 && hidden > 0 && n_splits >= 1 && n_splits <= 64, NVX_EINVAL, "nvx_rmsnorm_splitk: bad size");
+    if (rows == 0) return NVX_OK;
+    NVX_REQUIRE(partials && weight && y, NVX_EINVAL, "nvx_rmsnorm_splitk: null pointer");
+    NVX_REQUIRE(!residual || residual_out, NVX_EINVAL, "nvx_rmsnorm_splitk: residual without residual_out");
+    NVX_REQUIRE(hidden % 8 == 0 && hidden <= 8192, NVX_EUNSUPPORTED, "nvx_rmsnorm_splitk: hidden must be a multiple of 8, <= 8192 (got %lld)",
+                (long long)hidden);
+    NVX_REQUIRE(nvx_aligned16(partials) && nvx_aligned16(y) && nvx_aligned16(weight) &&
+                (!residual || (nvx_aligned16(residual) && nvx_aligned16(residual_out))),
+                NVX_EINVAL, "nvx_rmsnorm_splitk: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int h = (int)hidden, r = (int)rows;
+    if (h <= 512) launch_rmsnorm_splitk<1>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 1024) launch_rmsnorm_splitk<2>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 2048) launch_rmsnorm_splitk<4>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 4096) launch_rmsnorm_splitk<8>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 5120) launch_rmsnorm_splitk<10>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else launch_rmsnorm_splitk<16>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    return nvx_check_launch("nvx_rmsnorm_splitk");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rotary helpers.  A 128-wide head row is handled by 16 lanes; lane l holds elements 4l..4l+3 of
 // the first half (x1) and 64+4l..64+4l+3 of the second half (x2) and produces the interleaved

@@ -16,4 +16,8 @@ class RMSNorm(nn.Module):
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):
         """y = x * rsqrt(mean(x^2) + eps) * weight in fp32, rounded once; with `residual`, x + residual is
         normalised unrounded and returned rounded as the new residual: (y, residual)."""
+        if x.dtype == torch.float32 and x.dim() == 3:
+            # fp32 partial products (splits, rows, hidden) left by a K-split decode projection: the sum is
+            # rounded to bf16 first, which is what the unsplit projection would have handed over
+            return ops.rmsnorm_splitk(x, self.weight, self.variance_epsilon, residual)
         return ops.rmsnorm(x, self.weight, self.variance_epsilon, residual)

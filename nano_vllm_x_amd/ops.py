@@ -125,6 +125,51 @@ def qknorm_rope_store(qkv, positions, cos_sin_cache, q_norm_weight, k_norm_weigh
     return q_out
 
 
+def linear_decode_splits(n: int, k: int) -> int:
+    return int(_lib.load().nvx_linear_decode_splits(n, k))
+
+
+def linear_decode(x, w, mode: int = 0, k_splits: int = 1, out=None):
+    """x (m <= 256, k) bf16 times w (n, k)^T.  mode 0 -> bf16 (m, n); mode 1 -> SiluAndMul of the
+    [gate; up] projection, bf16 (m, n/2); mode 2 -> fp32 partials (k_splits, m, n) for rmsnorm_splitk."""
+    _dev(x, w, out)
+    _need(x.dim() == 2 and w.dim() == 2 and x.dtype == BF16 and w.dtype == BF16, "linear_decode: 2-D bf16 operands")
+    _need(x.stride(1) == 1 and w.is_contiguous() and x.shape[1] == w.shape[1], "linear_decode: layouts")
+    m, k = x.shape
+    n = w.shape[0]
+    if mode == 0:
+        shape, dtype = (m, n), BF16
+    elif mode == 1:
+        shape, dtype = (m, n // 2), BF16
+    else:
+        shape, dtype = (k_splits, m, n), torch.float32
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=x.device)
+    else:
+        _need(out.dtype == dtype and out.is_contiguous() and out.numel() >= shape[0] * shape[1] * (shape[2] if len(shape) == 3 else 1),
+              "linear_decode: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_linear_decode(_ptr(x), x.stride(0), _ptr(w), _ptr(out), m, n, k, mode, k_splits, _stream()), "nvx_linear_decode")
+    return out
+
+
+def rmsnorm_splitk(partials, weight, eps, residual=None):
+    """RMSNorm over bf16(sum of fp32 partials (splits, rows, hidden)); returns y or (y, new_residual)."""
+    _dev(partials, weight, residual)
+    _need(partials.dim() == 3 and partials.dtype == torch.float32 and partials.is_contiguous(), "rmsnorm_splitk: partials")
+    _need(weight.dtype == BF16 and weight.is_contiguous(), "rmsnorm_splitk: bf16 weight")
+    s, rows, hidden = partials.shape
+    y = torch.empty((rows, hidden), dtype=BF16, device=partials.device)
+    res_out = None
+    if residual is not None:
+        _need(residual.dtype == BF16 and residual.is_contiguous() and residual.shape == (rows, hidden), "rmsnorm_splitk: residual")
+        res_out = torch.empty_like(residual)
+    lib = _lib.load()
+    _lib.check(lib.nvx_rmsnorm_splitk(_ptr(partials), s, _ptr(residual), _ptr(weight), _ptr(y), _ptr(res_out), rows, hidden,
+                                      float(eps), _stream()), "nvx_rmsnorm_splitk")
+    return y if residual is None else (y, res_out)
+
+
 def silu_mul(x, out=None):
     """SiluAndMul.forward (activation.py:15-18)."""
     _dev(x)

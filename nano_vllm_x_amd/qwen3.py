@@ -22,6 +22,7 @@ from torch import nn
 from . import distributed as tpd
 from . import ops
 from .layers.activation import SiluAndMul
+from .core.common import ForwardMode
 from .layers.attention import Attention
 from .layers.layernorm import RMSNorm
 from .layers.rotary_embedding import RotaryEmbedding, build_cos_sin_cache
@@ -77,6 +78,34 @@ def load_config(model: str) -> Qwen3Config:
     raise FileNotFoundError(f"{cfg_file} not found and {name!r} is not one of {sorted(PRESETS)}")
 
 
+# Largest decode batch for which the skinny projection kernel (ops.linear_decode) beats the library
+# GEMM, per projection; measured on MI355X with the Qwen3-0.6B shapes (tools/kernel_bench.py linear).
+# Above these, and for every prefill, the projection is a library GEMM.
+DECODE_LINEAR_MAX_ROWS = {"qkv": 96, "o": 160, "gate_up": 224, "down": 96}
+
+
+def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
+    """Projection of a decode batch.  Returns bf16 (rows, n) -- or, for the row-parallel projections
+    ("o", "down") on a single rank, fp32 partial products (splits, rows, n) that the RMSNorm which
+    follows sums; "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
+    rows, k = x.shape
+    n = weight.shape[0]
+    use = x.is_cuda and x.dtype == torch.bfloat16 and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
+    if kind in ("o", "down"):
+        splits = ops.linear_decode_splits(n, k) if use and tpd.tp_size() == 1 and n % 16 == 0 else 0
+        if splits:
+            return ops.linear_decode(x, weight, mode=2, k_splits=splits)
+        return F.linear(x, weight)
+    fits = use and k in (512, 768, 1024)
+    if kind == "gate_up":
+        if fits and (n // 2) % 16 == 0:
+            return ops.linear_decode(x, weight, mode=1)
+        return ops.silu_mul(F.linear(x, weight))
+    if fits and n % 16 == 0:
+        return ops.linear_decode(x, weight, mode=0)
+    return F.linear(x, weight)
+
+
 def _shard(n: int, parts: int) -> int:
     assert n % parts == 0, f"{n} is not divisible by tensor-parallel size {parts}"
     return n // parts
@@ -104,8 +133,15 @@ class Qwen3Attention(nn.Module):
         self.rotary_emb: Optional[RotaryEmbedding] = None   # built on demand for the unfused path
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, fused: bool = True) -> torch.Tensor:
-        qkv = self.qkv_proj(hidden_states)
         md = self.attn.attention_metadata
+        if fused and md.forward_mode == ForwardMode.DECODE:
+            qkv = decode_linear(hidden_states, self.qkv_proj.weight, "qkv")
+            k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
+            q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
+                                      md.output_kv_indices, k_cache, v_cache, self.num_heads, self.num_kv_heads)
+            out = decode_linear(self.attn(q, None, None), self.o_proj.weight, "o")
+            return out if out.dtype == torch.float32 else tpd.tp_all_reduce(out)
+        qkv = self.qkv_proj(hidden_states)
         if fused:
             k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
             q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
@@ -130,7 +166,10 @@ class Qwen3MLP(nn.Module):
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
         self.act_fn = SiluAndMul()
 
-    def forward(self, x):
+    def forward(self, x, decode: bool = False):
+        if decode:
+            out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up"), self.down_proj.weight, "down")
+            return out if out.dtype == torch.float32 else tpd.tp_all_reduce(out)
         return tpd.tp_all_reduce(self.down_proj(self.act_fn(self.gate_up_proj(x))))
 
 
@@ -150,7 +189,8 @@ class Qwen3DecoderLayer(nn.Module):
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions, hidden_states, fused)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        return self.mlp(hidden_states), residual
+        md = self.self_attn.attn.attention_metadata
+        return self.mlp(hidden_states, decode=fused and md.forward_mode == ForwardMode.DECODE), residual
 
 
 class VocabParallelEmbedding(nn.Module):

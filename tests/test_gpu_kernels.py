@@ -438,3 +438,56 @@ def test_sampler_sliced_rows_draw_the_same_tokens(ops):
                         torch.empty(b, dtype=torch.int64, device=DEV).data_ptr(), small.data_ptr(), small.numel() * 8,
                         torch.cuda.current_stream().cuda_stream)
     assert rc == -4
+
+
+# -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 5, 16, 29, 64, 123, 256])
+@pytest.mark.parametrize("n,k", [(4096, 1024), (1024, 2048), (1024, 3072), (48, 512)])
+def test_linear_decode_matches_fp32_matmul(ops, m, n, k):
+    """fp32-accumulated MFMA product against torch fp32 matmul of the same bf16 operands: the only
+    difference is summation order, so |err| <= 2^-8 |ref| (output rounding) + 1e-3."""
+    gen = torch.Generator().manual_seed(m * 7 + n + k)
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(n, k, generator=gen) * k ** -0.5).to(torch.bfloat16).to(DEV)
+    want = x.float() @ w.float().t()
+    if k in (512, 768, 1024):    # one workgroup can hold the whole K slice: direct bf16 output
+        got = ops.linear_decode(x, w)
+        tol = want.abs() * 2.0 ** -8 + 1e-3
+        assert ((got.float() - want).abs() <= tol).all(), (got.float() - want).abs().max()
+    # split-K partials + the RMSNorm that sums them == RMSNorm of the unsplit projection
+    s = ops.linear_decode_splits(n, k)
+    assert s >= 1
+    if True:
+        parts = ops.linear_decode(x, w, mode=2, k_splits=s)
+        assert parts.shape == (s, m, n)
+        torch.testing.assert_close(parts.sum(0), want, rtol=1e-4, atol=1e-4)
+        if n % 8 == 0:
+            nw = torch.randn(n, generator=gen).to(torch.bfloat16).to(DEV)
+            res = torch.randn(m, n, generator=gen).to(torch.bfloat16).to(DEV)
+            y_ref, r_ref = ops.rmsnorm(parts.sum(0).to(torch.bfloat16), nw, 1e-6, residual=res)
+            y, r = ops.rmsnorm_splitk(parts, nw, 1e-6, residual=res)
+            assert bf16_ulp_diff(r, r_ref) <= 1 and bf16_ulp_diff(y, y_ref) <= 2
+            assert bf16_ulp_diff(ops.rmsnorm_splitk(parts, nw, 1e-6), ops.rmsnorm(parts.sum(0).to(torch.bfloat16), nw, 1e-6)) <= 2
+
+
+def test_linear_decode_strided_input_and_fused_silu(ops):
+    gen = torch.Generator().manual_seed(8)
+    m, k, inter = 37, 1024, 3072
+    wide = torch.randn(m, k + 64, generator=gen).to(torch.bfloat16).to(DEV)
+    x = wide[:, :k]                                     # rows 1088 elements apart
+    w = (torch.randn(2 * inter, k, generator=gen) * k ** -0.5).to(torch.bfloat16).to(DEV)
+    gu = ops.linear_decode(x, w)                        # plain projection ...
+    want = ops.silu_mul(gu)                             # ... then the stand-alone activation
+    got = ops.linear_decode(x, w, mode=1)
+    assert got.shape == (m, inter)
+    assert torch.equal(got, want)                       # same accumulation, same roundings: same bits
+
+
+def test_linear_decode_rejects_bad_shapes(ops):
+    x = torch.zeros(300, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="256 rows"):
+        ops.linear_decode(x, w)
+    with pytest.raises(RuntimeError, match="512, 768 or 1024"):
+        ops.linear_decode(x[:4], w)
+    assert ops.linear_decode_splits(64, 96) == 0

@@ -160,3 +160,60 @@ def test_prefix_reuse_generates_the_same_tokens_with_fewer_prefill_rows():
     assert results[True][0] == results[False][0]
     assert results[False][2] == 0 and results[True][2] == 6 * 24
     assert results[True][1] == results[False][1] - 6 * 24
+
+
+def test_decode_projections_fused_path_matches_library_gemm_path():
+    """A mid-size Qwen3 (hidden 512) whose decode projections qualify for ops.linear_decode (+ fused
+    SiluAndMul, + K-split partials summed inside RMSNorm) against the same model with every projection a
+    library GEMM (module flag fused=False runs the op-by-op graph).  Same bf16 operands, fp32
+    accumulation in both, different summation order: logits agree to 2^-6 * max|logit|."""
+    from nano_vllm_x_amd import qwen3
+    from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, Sequence
+    from nano_vllm_x_amd.core.model_runner import ModelRunner
+
+    cfg = qwen3.Qwen3Config(vocab_size=1024, hidden_size=512, intermediate_size=1536, num_hidden_layers=3,
+                            num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=256,
+                            tie_word_embeddings=False)
+    rng = np.random.default_rng(4)
+    prompts = [rng.integers(0, 1024, size=int(n)).tolist() for n in (5, 17, 33, 9, 21)]
+    outs = {}
+    calls = {"n": 0}
+    real = qwen3.ops.linear_decode
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    for fused in (True, False):
+        r = ModelRunner(model="mid", max_bs=8, enforce_eager=True, context_len=128, config=cfg, seed=3)
+        r.load_model()
+        r.model.fused = fused
+        r.initialize_kv_cache(512)
+        slot = 0
+        seqs = []
+        for i, p in enumerate(prompts):
+            seqs.append(Sequence(seq_id=f"m{i}", token_ids=list(p), num_tokens=len(p), prompt_len=len(p),
+                                 kv_indices=list(range(slot, slot + len(p)))))
+            slot += len(p) + 8
+        got = []
+        qwen3.ops.linear_decode = counting if fused else real
+        try:
+            for step in range(4):
+                mode = ForwardMode.PREFILL if step == 0 else ForwardMode.DECODE
+                logits = r.compute_logits(ForwardBatch(forward_mode=mode, num_seqs=len(seqs), seqs=seqs)).float().cpu().numpy()
+                got.append(logits)
+                for i, s in enumerate(seqs):
+                    s.cached_kv_len = len(s.kv_indices)
+                    s.token_ids.append(int(rng.integers(0, 1024)) if fused else outs["fed"][step][i])
+                    s.kv_indices.append(s.kv_indices[-1] + 1)
+                if fused:
+                    outs.setdefault("fed", []).append([s.token_ids[-1] for s in seqs])
+        finally:
+            qwen3.ops.linear_decode = real
+        outs[fused] = got
+    assert calls["n"] == 3 * 3 * 4, calls        # 3 decode steps x 3 layers x (qkv, o, gate_up, down)
+    for step in range(4):
+        a, b = outs[True][step], outs[False][step]
+        tol = 2.0 ** -6 * np.abs(b).max()
+        assert np.abs(a - b).max() <= tol, (step, np.abs(a - b).max(), tol)
+        assert (a.argmax(-1) == b.argmax(-1)).mean() >= 0.8

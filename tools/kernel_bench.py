@@ -161,12 +161,41 @@ def cmd_sampler(args):
                           "topk_topp_us": round(dt2 * 1e6, 1)}))
 
 
+def cmd_linear(args):
+    """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
+    import torch.nn.functional as F
+    shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up+silu", 6144, 1024, 1), ("down", 1024, 3072, 2)]
+    layers = 28
+    for m in (1, 8, 29, 64, 123, 256):
+        for name, n, k, mode in shapes:
+            ws = [(torch.randn(n, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(layers)]
+            x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+            s = ops.linear_decode_splits(n, k) if mode == 2 else 1
+            shape = (s, m, n) if mode == 2 else (m, n // 2 if mode == 1 else n)
+            out = torch.empty(shape, dtype=torch.float32 if mode == 2 else torch.bfloat16, device=DEV)
+            i = [0]
+
+            def ours():
+                ops.linear_decode(x, ws[i[0]], mode=mode, k_splits=s, out=out)
+                i[0] = (i[0] + 1) % layers
+
+            def lib():
+                y = F.linear(x, ws[i[0]])
+                if mode == 1:
+                    ops.silu_mul(y)
+                i[0] = (i[0] + 1) % layers
+
+            t_ours, t_lib = timed(ours, args.reps), timed(lib, args.reps)
+            print(json.dumps({"kernel": "linear_decode", "layer": name, "M": m, "N": n, "K": k, "splits": s, "us": round(t_ours * 1e6, 2),
+                              "hipblaslt_us": round(t_lib * 1e6, 2), "weight_GBps": round(n * k * 2 / t_ours / 1e9)}))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["decode", "prefill", "sampler"])
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear"])
     ap.add_argument("--every", type=int, default=8)
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--hkv1", action="store_true")
     a = ap.parse_args()
-    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler}[a.cmd](a)
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "linear": cmd_linear}[a.cmd](a)
