@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/nvx.h declares
+(no compute call is made here)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nvx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds():
+    from nano_vllm_x_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 20
+    assert set(_lib.SIGNATURES) | {"nvx_abi_version", "nvx_last_error"} >= set(names), set(names) - set(_lib.SIGNATURES)
+    assert set(_lib.SIGNATURES) <= set(names), set(_lib.SIGNATURES) - set(names)
+
+
+def test_library_exports_every_declared_symbol():
+    from nano_vllm_x_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "build first: make -C nano_vllm_x_amd/csrc"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/nvx.h but not exported"
+    lib.nvx_abi_version.restype = ctypes.c_int
+    assert lib.nvx_abi_version() >= 1
+    # pure host helpers answer without a device
+    lib.nvx_decode_plan_ws_ints.restype = ctypes.c_int64
+    lib.nvx_decode_plan_ws_ints.argtypes = [ctypes.c_int64, ctypes.c_int]
+    assert lib.nvx_decode_plan_ws_ints(256, 8) > 0
+    lib.nvx_linear_decode_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    assert lib.nvx_linear_decode_splits(1024, 3072) == 4 and lib.nvx_linear_decode_splits(4096, 1024) == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from nano_vllm_x_amd import _lib
+
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "absent.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    try:
+        _lib.load()
+    except _lib.NvxLibraryError as e:
+        assert "absent.so" in str(e) or "build" in str(e).lower()
+    else:
+        raise AssertionError("loading a missing library must raise")
