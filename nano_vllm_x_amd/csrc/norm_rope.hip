@@ -109,74 +109,69 @@ extern "C" int nvx_rmsnorm(const void* x, int64_t x_row_stride, const void* resi
 
 // RMSNorm whose input is the set of fp32 partial products a K-split linear layer left behind
 // (nvx_linear_decode mode 2): x = bf16(sum over splits), i.e. what the unsplit projection would have
-// stored, then the same arithmetic as rmsnorm_kernel.  One wave per row.
-template <int ITERS, bool HAS_RES>
+// stored, then the same arithmetic as rmsnorm_kernel.  Decode batches have few rows, so a whole
+// 256-thread workgroup takes one row (one wave per row would leave most of the chip idle and make
+// every lane walk splits x row/512 loads): thread t owns elements 4t .. 4t+3 of every 1024-wide
+// slab, all loads are issued at once, the sum of squares crosses the waves through LDS.
+template <int SLABS, bool HAS_RES>
 __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
     const float* __restrict__ partials, int n_splits, const uint16_t* residual, const uint16_t* __restrict__ weight,
     uint16_t* y, uint16_t* residual_out, int rows, int hidden, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
     const int64_t split_stride = (int64_t)rows * hidden;
-    float v[ITERS][8];
+    float v[SLABS][4];
     float ss = 0.f;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int col = it * 512 + lane * 8;
+    for (int it = 0; it < SLABS; ++it) {
+        const int col = it * 1024 + tid * 4;
         if (col < hidden) {
             const float* p = partials + (int64_t)row * hidden + col;
-            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < n_splits; ++s) {
-                const float4 lo = *reinterpret_cast<const float4*>(p + s * split_stride);
-                const float4 hi = *reinterpret_cast<const float4*>(p + s * split_stride + 4);
-                a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
-                a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+            float4 a = *reinterpret_cast<const float4*>(p);
+            for (int s = 1; s < n_splits; ++s) {
+                const float4 b = *reinterpret_cast<const float4*>(p + s * split_stride);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
             if (HAS_RES) {
-                const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)row * hidden + col);
-                const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
-                uint32_t ow[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = round_bf16(a[2 * j]) + bf16lo_to_f32(rw[j]);
-                    const float hi = round_bf16(a[2 * j + 1]) + bf16hi_to_f32(rw[j]);
-                    v[it][2 * j] = lo;
-                    v[it][2 * j + 1] = hi;
-                    ow[j] = pack_bf16x2(lo, hi);
-                }
-                *reinterpret_cast<uint4*>(residual_out + (int64_t)row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)row * hidden + col);
+                v[it][0] = round_bf16(a.x) + bf16lo_to_f32(r.x);
+                v[it][1] = round_bf16(a.y) + bf16hi_to_f32(r.x);
+                v[it][2] = round_bf16(a.z) + bf16lo_to_f32(r.y);
+                v[it][3] = round_bf16(a.w) + bf16hi_to_f32(r.y);
+                *reinterpret_cast<uint2*>(residual_out + (int64_t)row * hidden + col) =
+                    make_uint2(pack_bf16x2(v[it][0], v[it][1]), pack_bf16x2(v[it][2], v[it][3]));
             } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[it][j] = round_bf16(a[j]);
+                v[it][0] = round_bf16(a.x); v[it][1] = round_bf16(a.y); v[it][2] = round_bf16(a.z); v[it][3] = round_bf16(a.w);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+            for (int j = 0; j < 4; ++j) ss += v[it][j] * v[it][j];
         }
     }
     ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
     const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int col = it * 512 + lane * 8;
+    for (int it = 0; it < SLABS; ++it) {
+        const int col = it * 1024 + tid * 4;
         if (col < hidden) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(weight + col);
-            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
-            uint32_t ow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ow[j] = pack_bf16x2((v[it][2 * j] * inv) * bf16lo_to_f32(ww[j]), (v[it][2 * j + 1] * inv) * bf16hi_to_f32(ww[j]));
-            *reinterpret_cast<uint4*>(y + (int64_t)row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            const uint2 wv = *reinterpret_cast<const uint2*>(weight + col);
+            *reinterpret_cast<uint2*>(y + (int64_t)row * hidden + col) =
+                make_uint2(pack_bf16x2((v[it][0] * inv) * bf16lo_to_f32(wv.x), (v[it][1] * inv) * bf16hi_to_f32(wv.x)),
+                           pack_bf16x2((v[it][2] * inv) * bf16lo_to_f32(wv.y), (v[it][3] * inv) * bf16hi_to_f32(wv.y)));
         }
     }
 }
 
-template <int ITERS>
+template <int SLABS>
 static void launch_rmsnorm_splitk(const float* p, int s, const void* res, const void* w, void* y, void* ro, int rows, int hidden,
                                   float eps, hipStream_t st) {
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (res) hipLaunchKernelGGL((rmsnorm_splitk_kernel<ITERS, true>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+    const dim3 grid((unsigned)rows), block(256);
+    if (res) hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, true>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
                                 (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
-    else hipLaunchKernelGGL((rmsnorm_splitk_kernel<ITERS, false>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+    else hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, false>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
                             (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
 }
 
@@ -186,19 +181,18 @@ extern "C" int nvx_rmsnorm_splitk(const float* partials, int n_splits, const voi
     if (rows == 0) return NVX_OK;
     NVX_REQUIRE(partials && weight && y, NVX_EINVAL, "nvx_rmsnorm_splitk: null pointer");
     NVX_REQUIRE(!residual || residual_out, NVX_EINVAL, "nvx_rmsnorm_splitk: residual without residual_out");
-    NVX_REQUIRE(hidden % 8 == 0 && hidden <= 8192, NVX_EUNSUPPORTED, "nvx_rmsnorm_splitk: hidden must be a multiple of 8, <= 8192 (got %lld)",
+    NVX_REQUIRE(hidden % 4 == 0 && hidden <= 8192, NVX_EUNSUPPORTED, "nvx_rmsnorm_splitk: hidden must be a multiple of 4, <= 8192 (got %lld)",
                 (long long)hidden);
     NVX_REQUIRE(nvx_aligned16(partials) && nvx_aligned16(y) && nvx_aligned16(weight) &&
                 (!residual || (nvx_aligned16(residual) && nvx_aligned16(residual_out))),
                 NVX_EINVAL, "nvx_rmsnorm_splitk: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int h = (int)hidden, r = (int)rows;
-    if (h <= 512) launch_rmsnorm_splitk<1>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 1024) launch_rmsnorm_splitk<2>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 2048) launch_rmsnorm_splitk<4>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 4096) launch_rmsnorm_splitk<8>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 5120) launch_rmsnorm_splitk<10>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else launch_rmsnorm_splitk<16>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    if (h <= 1024) launch_rmsnorm_splitk<1>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 2048) launch_rmsnorm_splitk<2>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 4096) launch_rmsnorm_splitk<4>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 5120) launch_rmsnorm_splitk<5>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else launch_rmsnorm_splitk<8>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
     return nvx_check_launch("nvx_rmsnorm_splitk");
 }
 
