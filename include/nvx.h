@@ -135,15 +135,31 @@ int nvx_rmsnorm_splitk(const float* partials, int n_splits, const void* residual
  * (n_slots, n_kv_heads, 128) bf16 of one layer; out (batch, n_q_heads, 128) bf16 contiguous.
  * softmax(q.k * sm_scale) in fp32.  partial_ws: fp32 scratch for split sequences,
  * >= nvx_decode_partial_ws_floats() floats.  Rows with kv_len <= 0 produce zeros; slot ids outside
- * [0, n_slots) are treated as masked keys. */
+ * [0, n_slots) are treated as masked keys.
+ *
+ * nvx_paged_decode_qkv is the same attention fed with the raw fused projection of the step instead of
+ * finished queries: qkv (batch, (n_q_heads + 2*n_kv_heads)*128) as in nvx_qknorm_rope_store.  The
+ * kernel applies the per-head RMSNorm and rotary embedding to the query heads itself and, for every
+ * sequence whose out_slots[b] >= 0 was given to nvx_decode_plan, does the same for the new key,
+ * writes the new k/v row to slot out_slots[b] and attends to it from registers; that row must be
+ * the last entry of the sequence's slot list.  One launch replaces nvx_qknorm_rope_store +
+ * nvx_paged_decode (nanovllmx/models/qwen3.py:123-133 + layers/attention.py:344-369).
+ * out_slots may be NULL in nvx_decode_plan when only nvx_paged_decode is used. */
 int64_t nvx_decode_plan_ws_ints(int64_t max_batch, int n_kv_heads);
 int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads, int n_kv_heads);
-int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, int64_t batch, int n_kv_heads,
-                    int32_t* plan_ws, int64_t plan_ws_ints, nvx_stream_t stream);
+int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, const int64_t* out_slots,
+                    int64_t batch, int n_kv_heads, int32_t* plan_ws, int64_t plan_ws_ints,
+                    nvx_stream_t stream);
 int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
                      int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws,
                      float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
                      float sm_scale, nvx_stream_t stream);
+int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+                         const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
+                         const void* k_norm_weight, float eps, void* k_cache, void* v_cache,
+                         int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws,
+                         float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                         float sm_scale, nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Paged attention, prefill: causal, variable-length, queries right-aligned to the keys.

@@ -25,7 +25,9 @@ SIGNATURES = {
     "nvx_silu_mul": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "nvx_decode_plan_ws_ints": (_c_i64, [_c_i64, _c_i32]),
     "nvx_decode_partial_ws_floats": (_c_i64, [_c_i64, _c_i32, _c_i32]),
-    "nvx_decode_plan": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_i32, _c_vp, _c_i64, _c_vp]),
+    "nvx_decode_plan": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i32, _c_vp, _c_i64, _c_vp]),
+    "nvx_paged_decode_qkv": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_f32, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp,
+                                      _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_f32, _c_vp]),
     "nvx_paged_decode": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64,
                                   _c_i32, _c_i32, _c_f32, _c_vp]),
     "nvx_prefill_plan_ws_ints": (_c_i64, [_c_i64]),

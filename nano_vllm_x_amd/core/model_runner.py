@@ -205,7 +205,7 @@ class ModelRunner:
         bt = self.block_table
         ops.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
                               bt.positions, bt.input_ids)
-        ops.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], self.decode_ws)
+        ops.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], self.decode_ws, out_slots=bt.out_slots[:bs])
         wrapper = self._graph_wrappers[bs]
         md = AttentionMetadata(forward_mode=ForwardMode.DECODE, kv_cache=self.kv_cache, output_kv_indices=bt.out_slots[:bs],
                                wrapper=wrapper)
@@ -232,7 +232,7 @@ class ModelRunner:
         with torch.cuda.stream(side):
             for bs in reversed(sizes):
                 w = PagedDecodeWrapper(None, "NHD", use_cuda_graph=True)
-                w.bind_table(bt.table.view(-1), bt.kv_start, bt.kv_len, bs, self.decode_ws)
+                w.bind_table(bt.table.view(-1), bt.kv_start, bt.kv_len, bs, self.decode_ws, qkv_fused=True)
                 self._graph_wrappers[bs] = w
                 self._decode_forward(bs)   # warm-up outside capture (library handles, allocator pool)
         torch.cuda.current_stream().wait_stream(side)

@@ -17,12 +17,13 @@
 //   * quarter-waves are merged by wave shuffles, waves through LDS; sequences split over several
 //     chunks leave (m, l, acc) partials that a small second kernel combines.
 #include "nvx_dev.h"
+#include "rope_dev.h"
 
 #define DEC_TARGET_UNITS 2048   // work units (chunk x kv head) the plan aims for
 #define DEC_MIN_CHUNK 128       // tokens
 #define DEC_MAX_CHUNK (1 << 24) // tokens: "do not split"
 #define DEC_PART_STRIDE 132     // floats per (item, q head): 128 acc + m + l (+2 pad)
-#define DEC_REC_INTS 8          // per item: seq, n_tokens, n_chunks_of_seq, chunk_index, abs_lo, abs_hi, 0, 0
+#define DEC_REC_INTS 8          // per item: seq, n_tokens, n_chunks_of_seq, chunk_index, abs_lo, abs_hi, 0, new_slot
 #define DEC_LOG2E 1.4426950408889634f
 
 static inline int64_t dec_max_items(int64_t max_batch, int n_kv_heads) {
@@ -39,7 +40,8 @@ extern "C" int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads
 // plan_ws layout (int32): [0] n_items, [1] chunk, [2] batch, [3] max_items, [4..7] reserved,
 //   records[max_items][8], seq_first[batch], seq_nchunks[batch]
 __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __restrict__ kv_len,
-                                                           const int64_t* __restrict__ kv_start, int batch, int hkv,
+                                                           const int64_t* __restrict__ kv_start,
+                                                           const int64_t* __restrict__ out_slots, int batch, int hkv,
                                                            int32_t* __restrict__ ws, int max_items, int target_units) {
     __shared__ long long red[16];
     __shared__ int scan[1024];
@@ -80,13 +82,16 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
             seq_first[b] = first;
             seq_nch[b] = nch;
             const int64_t start = kv_start[b];
+            // slot the new token's K/V row goes to, recorded on the sequence's last chunk (QKV variant)
+            long long new_slot = out_slots ? out_slots[b] : -1;
+            if (new_slot < 0 || new_slot > 0x7fffffffll || len == 0) new_slot = -1;
             for (int i = 0; i < nch && first + i < max_items; ++i) {
                 const long long left = (long long)len - (long long)i * chunk;
                 const int n = (int)(left > chunk ? chunk : left);
                 const int64_t abs = start + (int64_t)i * chunk;
                 int32_t* r = recs + (int64_t)DEC_REC_INTS * (first + i);
                 r[0] = b; r[1] = n; r[2] = nch; r[3] = i;
-                r[4] = (int32_t)(abs & 0xffffffffll); r[5] = (int32_t)(abs >> 32); r[6] = 0; r[7] = 0;
+                r[4] = (int32_t)(abs & 0xffffffffll); r[5] = (int32_t)(abs >> 32); r[6] = 0; r[7] = i == nch - 1 ? (int32_t)new_slot : -1;
             }
         }
         __syncthreads();
@@ -101,14 +106,14 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
     }
 }
 
-extern "C" int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, int64_t batch, int n_kv_heads,
-                               int32_t* plan_ws, int64_t plan_ws_ints, nvx_stream_t stream) {
+extern "C" int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, const int64_t* out_slots, int64_t batch,
+                               int n_kv_heads, int32_t* plan_ws, int64_t plan_ws_ints, nvx_stream_t stream) {
     NVX_REQUIRE(batch > 0 && n_kv_heads > 0, NVX_EINVAL, "nvx_decode_plan: bad size");
     NVX_REQUIRE(kv_len && kv_start && plan_ws, NVX_EINVAL, "nvx_decode_plan: null pointer");
     NVX_REQUIRE(plan_ws_ints >= nvx_decode_plan_ws_ints(batch, n_kv_heads), NVX_ENOSPACE,
                 "nvx_decode_plan: plan workspace too small (%lld < %lld ints)", (long long)plan_ws_ints,
                 (long long)nvx_decode_plan_ws_ints(batch, n_kv_heads));
-    hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_len, kv_start, (int)batch,
+    hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_len, kv_start, out_slots, (int)batch,
                        n_kv_heads, plan_ws, (int)dec_max_items(batch, n_kv_heads), DEC_TARGET_UNITS);
     return nvx_check_launch("nvx_decode_plan");
 }
@@ -144,8 +149,10 @@ __device__ __forceinline__ void dec_issue(DecTile<TPQ>& t, const int (&slots)[TP
         slot = ok ? slot : 0u;
         t.ok |= ok ? (1u << u) : 0u;
         const unsigned long long off = (unsigned long long)slot * row_bytes;
-        t.k[u] = *reinterpret_cast<const nvx_u32x4*>(kb + off);
-        t.v[u] = *reinterpret_cast<const nvx_u32x4*>(vb + off);
+        // every K/V byte is used once per launch: streaming (non-temporal) loads keep them from
+        // displacing the block table and the partials in L2 (measured: 29.0 -> 26.2 us per launch)
+        t.k[u] = __builtin_nontemporal_load(reinterpret_cast<const nvx_u32x4*>(kb + off));
+        t.v[u] = __builtin_nontemporal_load(reinterpret_cast<const nvx_u32x4*>(vb + off));
     }
 }
 
@@ -195,13 +202,38 @@ __device__ __forceinline__ void dec_compute(const DecTile<TPQ>& t, const nvx_u32
     }
 }
 
+// What the kernel needs to make its own query and new key from the raw fused projection (QKV variant):
+// per-head RMSNorm + rotary embedding of q and k, and the scatter of the new k/v row.
+struct DecQkv {
+    const int64_t* positions;   // (batch)
+    const float* cos_sin;       // (max_pos, 128) fp32
+    int64_t max_pos;
+    const uint16_t* q_weight;   // (128) bf16
+    const uint16_t* k_weight;
+    float eps;
+    uint16_t* k_cache_w;        // same pools, writable
+    uint16_t* v_cache_w;
+};
+
+__device__ __forceinline__ nvx_u32x4 dec_new_key(const uint16_t* row, int hq_total, int head, const DecQkv& fx, const float* cs,
+                                                 int piece) {
+    const HalfQuad x = load_half_quads(row + (hq_total + head) * 128, piece);
+    const uint4 o = norm_rotate_interleave(x, half_quad_sumsq(x), fx.k_weight, fx.eps, cs, piece);
+    return nvx_u32x4{o.x, o.y, o.z, o.w};
+}
+
 // G = query heads per kv head, TPQ = tokens per quarter-wave per tile (a wave's tile is 4*TPQ tokens).
-template <int G, int TPQ>
-__global__ __launch_bounds__(256) void paged_decode_kernel(
+// QKV = false: q holds finished queries (batch, G*hkv, 128).
+// QKV = true:  q holds the raw projection rows [q heads | k heads | v heads]; the kernel normalises and
+//   rotates its own query heads, and the workgroup that owns a sequence's last chunk does the same for
+//   the new key, writes the new k/v row into the pool and attends to it from registers (the row is the
+//   last entry of the sequence's slot list and is skipped when reading the pool).
+template <int G, int TPQ, bool QKV>
+__global__ __launch_bounds__(256, (G <= 2 ? 4 : 2)) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ plan, float* __restrict__ partial, uint16_t* __restrict__ out, int hkv,
-    float scale_log2) {
+    float scale_log2, DecQkv fx) {
     constexpr int TILE = 4 * TPQ;
     constexpr int STEP = 4 * TILE;   // four waves interleave their tiles
     __shared__ float lds[4][G][16][10];  // [wave][head in group][piece] -> m, l, acc[8]
@@ -228,14 +260,30 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         const char* kb = reinterpret_cast<const char*>(k_cache) + head * 256 + piece * 16;
         const char* vb = reinterpret_cast<const char*>(v_cache) + head * 256 + piece * 16;
 
+        // QKV variant: the last chunk of a sequence whose new row's slot is in the record attends to that
+        // row from registers and reads one token less from the pool
+        const int slot_new = QKV ? __builtin_amdgcn_readfirstlane((int)r1[3]) : -1;
+        const bool own_new = QKV && slot_new >= 0 && (long long)slot_new < (long long)n_slots && n > 0;
+        const int n_pool = own_new ? n - 1 : n;
+
+        // dependent chain: record -> slot ids -> K/V rows.  The query (and, in the QKV variant, its
+        // norm and rotation) is fetched beside the slot ids and finished while the first rows fly.
         int slots[TPQ];
         int tile = wave * TILE;
-        dec_load_slots<TPQ>(slots, idx_base, tile, quarter, n);
+        dec_load_slots<TPQ>(slots, idx_base, tile, quarter, n_pool);
 
         nvx_u32x4 qv[G];
+        HalfQuad qraw[QKV ? G : 1];
+        const uint16_t* qrow = q + (int64_t)b * q_stride;
+        const float* cs = nullptr;
+        if (QKV) {
+            cs = fx.cos_sin + clamp_pos(fx.positions[b], fx.max_pos) * 128;
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            qv[g] = *reinterpret_cast<const nvx_u32x4*>(q + (int64_t)b * q_stride + (head * G + g) * 128 + piece * 8);
+            for (int g = 0; g < G; ++g) qraw[g] = load_half_quads(qrow + (head * G + g) * 128, piece);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const nvx_u32x4*>(qrow + (head * G + g) * 128 + piece * 8);
+        }
 
         float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -249,11 +297,62 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         // reduced.  (Keeping a second tile of rows in flight per wave was measured slower: the registers
         // it takes halve the number of resident waves.)
         DecTile<TPQ> ta;
-        while (tile < n) {
+        if (QKV) {   // first tile peeled: the query is finished between the issue of its rows and their use
+            const bool any = tile < n_pool;
+            if (any) {
+                dec_issue<TPQ>(ta, slots, kb, vb, row_bytes, n_slots_u);
+                dec_load_slots<TPQ>(slots, idx_base, tile + STEP, quarter, n_pool);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint4 o = norm_rotate_interleave(qraw[g], half_quad_sumsq(qraw[g]), fx.q_weight, fx.eps, cs, piece);
+                qv[g] = nvx_u32x4{o.x, o.y, o.z, o.w};
+            }
+            if (any) {
+                dec_compute<G, TPQ>(ta, qv, m, l, acc, scale_log2);
+                tile += STEP;
+            }
+        }
+        while (tile < n_pool) {
             dec_issue<TPQ>(ta, slots, kb, vb, row_bytes, n_slots_u);
-            dec_load_slots<TPQ>(slots, idx_base, tile + STEP, quarter, n);
+            dec_load_slots<TPQ>(slots, idx_base, tile + STEP, quarter, n_pool);
             dec_compute<G, TPQ>(ta, qv, m, l, acc, scale_log2);
             tile += STEP;
+        }
+
+        if (QKV && own_new) {   // the new token: made from the raw projection, stored, and attended to from
+                                // registers, counted once (wave 0, quarter 0)
+            const bool mine = wave == 0 && quarter == 0;
+            const nvx_u32x4 k_new = dec_new_key(qrow, hq_total, head, fx, cs, piece);
+            const nvx_u32x4 v_new = *reinterpret_cast<const nvx_u32x4*>(qrow + (hq_total + hkv + head) * 128 + piece * 8);
+            if (tid < 16) {
+                const int64_t at = ((int64_t)slot_new * hkv + head) * 128 + piece * 8;
+                *reinterpret_cast<nvx_u32x4*>(fx.k_cache_w + at) = k_new;
+                *reinterpret_cast<nvx_u32x4*>(fx.v_cache_w + at) = v_new;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned qw = qv[g][w], kw = k_new[w];
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nvx_bf16x2, qw), __builtin_bit_cast(nvx_bf16x2, kw), d, false);
+                }
+                d = quarter_sum(d);
+                const float sc = mine ? d * scale_log2 : -INFINITY;
+                const float mx = fmaxf(m[g], sc);
+                const float mref = mx == -INFINITY ? 0.f : mx;
+                const float alpha = __builtin_amdgcn_exp2f(m[g] - mref);
+                const float pr = __builtin_amdgcn_exp2f(sc - mref);
+                m[g] = mx;
+                l[g] = l[g] * alpha + pr;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned vw = mine ? (unsigned)v_new[w] : 0u;
+                    acc[g][2 * w] = acc[g][2 * w] * alpha + pr * bf16lo_to_f32(vw);
+                    acc[g][2 * w + 1] = acc[g][2 * w + 1] * alpha + pr * bf16hi_to_f32(vw);
+                }
+            }
         }
 
         // merge the four quarter-waves (they hold different tokens, same dims)
@@ -348,36 +447,65 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const int32_t* __rest
     out[((int64_t)b * hq_total + hq) * 128 + d] = f32_to_bf16bits(lsum > 0.f ? o / lsum : 0.f);
 }
 
-extern "C" int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
-                                int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws, float* partial_ws,
-                                void* out, int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale,
-                                nvx_stream_t stream) {
-    NVX_REQUIRE(batch > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_slots > 0, NVX_EINVAL, "nvx_paged_decode: bad size");
-    NVX_REQUIRE(q && k_cache && v_cache && kv_indices && plan_ws && partial_ws && out, NVX_EINVAL,
-                "nvx_paged_decode: null pointer");
-    NVX_REQUIRE(n_q_heads % n_kv_heads == 0, NVX_EINVAL, "nvx_paged_decode: n_q_heads must be a multiple of n_kv_heads");
-    NVX_REQUIRE(q_row_stride % 8 == 0 && q_row_stride >= (int64_t)n_q_heads * 128, NVX_EINVAL, "nvx_paged_decode: bad q row stride");
+static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache, int64_t n_slots,
+                      const int32_t* kv_indices, const int32_t* plan_ws, float* partial_ws, void* out, int64_t batch, int n_q_heads,
+                      int n_kv_heads, float sm_scale, const DecQkv* fx, int min_q_width, const char* who, nvx_stream_t stream) {
+    NVX_REQUIRE(batch > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_slots > 0, NVX_EINVAL, "%s: bad size", who);
+    NVX_REQUIRE(q && k_cache && v_cache && kv_indices && plan_ws && partial_ws && out, NVX_EINVAL, "%s: null pointer", who);
+    NVX_REQUIRE(n_q_heads % n_kv_heads == 0, NVX_EINVAL, "%s: n_q_heads must be a multiple of n_kv_heads", who);
+    NVX_REQUIRE(q_row_stride % 8 == 0 && q_row_stride >= (int64_t)min_q_width, NVX_EINVAL, "%s: bad row stride", who);
     NVX_REQUIRE(nvx_aligned16(q) && nvx_aligned16(k_cache) && nvx_aligned16(v_cache) && nvx_aligned16(out) &&
-                nvx_aligned16(partial_ws) && nvx_aligned16(plan_ws), NVX_EINVAL, "nvx_paged_decode: pointers must be 16-byte aligned");
+                nvx_aligned16(partial_ws) && nvx_aligned16(plan_ws), NVX_EINVAL, "%s: pointers must be 16-byte aligned", who);
     const int g = n_q_heads / n_kv_heads;
     const float scale_log2 = sm_scale * DEC_LOG2E;
     hipStream_t st = (hipStream_t)stream;
     const int64_t max_units = dec_max_items(batch, n_kv_heads) * n_kv_heads;
-    unsigned grid = (unsigned)(max_units < 2048 ? max_units : 2048);
-#define NVX_DEC(GG, TT) hipLaunchKernelGGL((paged_decode_kernel<GG, TT>), dim3(grid), dim3(256), 0, st, (const uint16_t*)q,    \
-        q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, partial_ws,             \
-        (uint16_t*)out, n_kv_heads, scale_log2)
+    const unsigned grid = (unsigned)(max_units < 2048 ? max_units : 2048);
+    const DecQkv none = {};
+#define NVX_DEC(GG, TT, TQ)                                                                                                      \
+    do {                                                                                                                         \
+        if (fx) hipLaunchKernelGGL((paged_decode_kernel<GG, TQ, true>), dim3(grid), dim3(256), 0, st, (const uint16_t*)q, q_row_stride, \
+                                   (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, partial_ws, \
+                                   (uint16_t*)out, n_kv_heads, scale_log2, *fx);                                                 \
+        else hipLaunchKernelGGL((paged_decode_kernel<GG, TT, false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)q, q_row_stride,  \
+                                (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, partial_ws,    \
+                                (uint16_t*)out, n_kv_heads, scale_log2, none);                                                   \
+    } while (0)
+    // tokens per quarter-wave per tile: plain variant / variant fed with the raw projection (which keeps
+    // more values live across the loop, so it takes a smaller tile to stay within the same registers)
     switch (g) {
-        case 1: NVX_DEC(1, 8); break;
-        case 2: NVX_DEC(2, 8); break;
-        case 4: NVX_DEC(4, 4); break;
-        case 8: NVX_DEC(8, 2); break;
-        default: return nvx_fail(NVX_EUNSUPPORTED, "nvx_paged_decode: query/kv head ratio %d not in {1,2,4,8}", g);
+        case 1: NVX_DEC(1, 4, 4); break;
+        case 2: NVX_DEC(2, 4, 2); break;   // plain: 112 VGPRs, four workgroups per CU; measured best of TPQ 2/4/8/16
+        case 4: NVX_DEC(4, 4, 2); break;
+        case 8: NVX_DEC(8, 2, 2); break;
+        default: return nvx_fail(NVX_EUNSUPPORTED, "%s: query/kv head ratio %d not in {1,2,4,8}", who, g);
     }
 #undef NVX_DEC
-    int rc = nvx_check_launch("nvx_paged_decode");
+    int rc = nvx_check_launch(who);
     if (rc) return rc;
     hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * n_q_heads)), dim3(128), 0, st, plan_ws, partial_ws,
                        (uint16_t*)out, n_q_heads);
-    return nvx_check_launch("nvx_paged_decode(merge)");
+    return nvx_check_launch(who);
+}
+
+extern "C" int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                                int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws, float* partial_ws,
+                                void* out, int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale,
+                                nvx_stream_t stream) {
+    return dec_launch(q, q_row_stride, k_cache, v_cache, n_slots, kv_indices, plan_ws, partial_ws, out, batch, n_q_heads,
+                      n_kv_heads, sm_scale, nullptr, n_q_heads * 128, "nvx_paged_decode", stream);
+}
+
+extern "C" int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                                    int64_t max_pos, const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                    void* k_cache, void* v_cache, int64_t n_slots, const int32_t* kv_indices,
+                                    const int32_t* plan_ws, float* partial_ws, void* out, int64_t batch, int n_q_heads,
+                                    int n_kv_heads, float sm_scale, nvx_stream_t stream) {
+    NVX_REQUIRE(positions && cos_sin && q_norm_weight && k_norm_weight && max_pos > 0, NVX_EINVAL, "nvx_paged_decode_qkv: null pointer");
+    NVX_REQUIRE(nvx_aligned16(cos_sin) && nvx_aligned16(q_norm_weight) && nvx_aligned16(k_norm_weight), NVX_EINVAL,
+                "nvx_paged_decode_qkv: pointers must be 16-byte aligned");
+    const DecQkv fx = {positions, cos_sin, max_pos, (const uint16_t*)q_norm_weight, (const uint16_t*)k_norm_weight, eps,
+                       (uint16_t*)k_cache, (uint16_t*)v_cache};
+    return dec_launch(qkv, qkv_row_stride, k_cache, v_cache, n_slots, kv_indices, plan_ws, partial_ws, out, batch, n_q_heads,
+                      n_kv_heads, sm_scale, &fx, (n_q_heads + 2 * n_kv_heads) * 128, "nvx_paged_decode_qkv", stream);
 }

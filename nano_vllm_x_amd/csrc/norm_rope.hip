@@ -2,6 +2,7 @@
 // All four are HBM-bound streaming kernels: 16-byte loads/stores per lane, fp32 math in registers,
 // wave64 shuffles for the row reductions, no LDS.
 #include "nvx_dev.h"
+#include "rope_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // RMSNorm: one wave per row, the row stays in registers between the two passes.
@@ -196,42 +197,6 @@ extern "C" int nvx_rmsnorm_splitk(const float* partials, int n_splits, const voi
     return nvx_check_launch("nvx_rmsnorm_splitk");
 }
 
-// ---------------------------------------------------------------------------------------------
-// Rotary helpers.  A 128-wide head row is handled by 16 lanes; lane l holds elements 4l..4l+3 of
-// the first half (x1) and 64+4l..64+4l+3 of the second half (x2) and produces the interleaved
-// outputs 8l..8l+7 = (o1_0, o2_0, o1_1, o2_1, ...): one 16-byte store.
-// ---------------------------------------------------------------------------------------------
-struct HalfQuad { float a[4]; float b[4]; };
-
-__device__ __forceinline__ HalfQuad load_half_quads(const uint16_t* row, int l16) {
-    const uint2 p = *reinterpret_cast<const uint2*>(row + 4 * l16);
-    const uint2 q = *reinterpret_cast<const uint2*>(row + 64 + 4 * l16);
-    HalfQuad h;
-    h.a[0] = bf16lo_to_f32(p.x); h.a[1] = bf16hi_to_f32(p.x); h.a[2] = bf16lo_to_f32(p.y); h.a[3] = bf16hi_to_f32(p.y);
-    h.b[0] = bf16lo_to_f32(q.x); h.b[1] = bf16hi_to_f32(q.x); h.b[2] = bf16lo_to_f32(q.y); h.b[3] = bf16hi_to_f32(q.y);
-    return h;
-}
-
-// Eager bf16 arithmetic: cos/sin rounded to bf16, every product and sum rounded to bf16.
-__device__ __forceinline__ uint4 rotate_interleave(const HalfQuad& x, const float* cs_row, int l16) {
-    const float4 c4 = *reinterpret_cast<const float4*>(cs_row + 4 * l16);
-    const float4 s4 = *reinterpret_cast<const float4*>(cs_row + 64 + 4 * l16);
-    const float c[4] = {round_bf16(c4.x), round_bf16(c4.y), round_bf16(c4.z), round_bf16(c4.w)};
-    const float s[4] = {round_bf16(s4.x), round_bf16(s4.y), round_bf16(s4.z), round_bf16(s4.w)};
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float o1 = round_bf16(x.a[j] * c[j]) - round_bf16(x.b[j] * s[j]);
-        const float o2 = round_bf16(x.b[j] * c[j]) + round_bf16(x.a[j] * s[j]);
-        o[j] = pack_bf16x2(o1, o2);
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-__device__ __forceinline__ int64_t clamp_pos(int64_t p, int64_t max_pos) {
-    return p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
-}
-
 __global__ __launch_bounds__(256) void rope_kernel(
     const int64_t* __restrict__ positions, const float* __restrict__ cos_sin, int64_t max_pos,
     const uint16_t* q, int64_t q_stride, const uint16_t* k, int64_t k_stride, uint16_t* q_out, uint16_t* k_out,
@@ -300,20 +265,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     }
     const bool is_q = h < hq;
     if (!is_q && !slot_ok) return;
-    const uint16_t* w = is_q ? qw : kw;
-    const uint2 wa = *reinterpret_cast<const uint2*>(w + 4 * l16);
-    const uint2 wb = *reinterpret_cast<const uint2*>(w + 64 + 4 * l16);
-    const float wA[4] = {bf16lo_to_f32(wa.x), bf16hi_to_f32(wa.x), bf16lo_to_f32(wa.y), bf16hi_to_f32(wa.y)};
-    const float wB[4] = {bf16lo_to_f32(wb.x), bf16hi_to_f32(wb.x), bf16lo_to_f32(wb.y), bf16hi_to_f32(wb.y)};
-    const float inv = 1.0f / sqrtf(ss / 128.0f + eps);
-    HalfQuad n;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // the unfused norm hands bf16 to the rotary op
-        n.a[j] = round_bf16((x.a[j] * inv) * wA[j]);
-        n.b[j] = round_bf16((x.b[j] * inv) * wB[j]);
-    }
     const float* cs = cos_sin + clamp_pos(positions[tok], max_pos) * 128;
-    const uint4 o = rotate_interleave(n, cs, l16);
+    const uint4 o = norm_rotate_interleave(x, ss, is_q ? qw : kw, eps, cs, l16);
     uint16_t* dst = is_q ? q_out + (tok * hq + h) * 128 : k_cache + (slot * hkv + (h - hq)) * 128;
     *reinterpret_cast<uint4*>(dst + 8 * l16) = o;
 }

@@ -113,6 +113,7 @@ class PagedDecodeWrapper:
         self._ws: Optional[ops.DecodeWorkspace] = None
         self._kv_start = self._kv_len = self._kv_indices = None
         self._batch = 0
+        self.qkv_fused = False
 
     def _ensure(self, batch: int, hq: int, hkv: int, device):
         if self._ws is None or self._ws.max_batch < batch or (self._ws.n_q_heads, self._ws.n_kv_heads) != (hq, hkv):
@@ -133,10 +134,19 @@ class PagedDecodeWrapper:
         self._kv_indices = indices if not self._static or self._indices_buf is None else self._indices_buf
         ops.decode_plan(self._kv_len[:b], self._kv_start[:b], self._ws)
 
-    def bind_table(self, kv_indices, kv_start, kv_len, batch: int, ws: ops.DecodeWorkspace):
+    def bind_table(self, kv_indices, kv_start, kv_len, batch: int, ws: ops.DecodeWorkspace, qkv_fused: bool = False):
         """Use caller-owned static buffers (the device-resident block table); the plan kernel is then
-        launched by the caller as part of its captured graph."""
+        launched by the caller as part of its captured graph.  `qkv_fused` says that the caller's plan
+        carries the new rows' slots, so run_qkv may be used."""
         self._kv_indices, self._kv_start, self._kv_len, self._batch, self._ws = kv_indices, kv_start, kv_len, batch, ws
+        self.qkv_fused = qkv_fused
+
+    def run_qkv(self, qkv, positions, cos_sin_cache, q_weight, k_weight, eps, paged_kv_cache, out=None):
+        """Attention straight from the raw fused projection (see ops.paged_decode_qkv): replaces the
+        q/k norm + rotary + scatter launch and run()."""
+        k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)
+        return ops.paged_decode_qkv(qkv, positions, cos_sin_cache, q_weight, k_weight, eps, k_cache, v_cache, self._kv_indices,
+                                    self._batch, self._ws, self._sm_scale if self._sm_scale is not None else 128 ** -0.5, out=out)
 
     def run(self, q, paged_kv_cache, out=None):
         k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)

@@ -197,15 +197,48 @@ class DecodeWorkspace:
                                    device=device)
 
 
-def decode_plan(kv_len, kv_start, ws: DecodeWorkspace):
-    """Cut the batch's sequences into chunks (device side); must precede paged_decode of the same step."""
-    _dev(kv_len, kv_start)
+def decode_plan(kv_len, kv_start, ws: DecodeWorkspace, out_slots=None):
+    """Cut the batch's sequences into chunks (device side); must precede paged_decode of the same step.
+    `out_slots` (int64 per sequence, -1 = none) is needed by paged_decode_qkv: the slot the step's new
+    K/V row goes to."""
+    _dev(kv_len, kv_start, out_slots)
     b = kv_len.numel()
+    if out_slots is not None:
+        _need(out_slots.dtype == torch.int64 and out_slots.is_contiguous() and out_slots.numel() == b, "decode_plan: out_slots")
     _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and 0 < b <= ws.max_batch, "decode_plan: kv_len")
     _need(kv_start.dtype == torch.int64 and kv_start.is_contiguous() and kv_start.numel() == b, "decode_plan: kv_start")
     lib = _lib.load()
-    _lib.check(lib.nvx_decode_plan(_ptr(kv_len), _ptr(kv_start), b, ws.n_kv_heads, _ptr(ws.plan), ws.plan.numel(), _stream()),
-               "nvx_decode_plan")
+    _lib.check(lib.nvx_decode_plan(_ptr(kv_len), _ptr(kv_start), _ptr(out_slots), b, ws.n_kv_heads, _ptr(ws.plan), ws.plan.numel(),
+                                   _stream()), "nvx_decode_plan")
+
+
+def paged_decode_qkv(qkv, positions, cos_sin_cache, q_weight, k_weight, eps, k_cache, v_cache, kv_indices, batch: int,
+                     ws: DecodeWorkspace, sm_scale, out=None):
+    """Decode attention fed with the raw fused projection (B, (Hq + 2*Hkv)*128): per-head RMSNorm + rotary
+    of q and of the new k, scatter of the new k/v row (to the slots given to decode_plan) and attention,
+    in one launch.  Equivalent to qknorm_rope_store followed by paged_decode."""
+    _dev(qkv, positions, cos_sin_cache, q_weight, k_weight, k_cache, v_cache, kv_indices)
+    b = batch
+    hq, hkv = ws.n_q_heads, ws.n_kv_heads
+    _need(qkv.dim() == 2 and qkv.shape[0] == b and qkv.shape[1] == (hq + 2 * hkv) * 128 and qkv.dtype == BF16 and qkv.stride(1) == 1,
+          "paged_decode_qkv: qkv layout")
+    _need(positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == b, "paged_decode_qkv: positions")
+    _need(cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == 128,
+          "paged_decode_qkv: cos/sin table")
+    _need(q_weight.dtype == BF16 and k_weight.dtype == BF16 and q_weight.numel() == 128 and k_weight.numel() == 128,
+          "paged_decode_qkv: norm weights")
+    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+          tuple(k_cache.shape[-2:]) == (hkv, 128) and v_cache.shape == k_cache.shape, "paged_decode_qkv: cache layout")
+    _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode_qkv: kv_indices must be int32")
+    _need(0 < b <= ws.max_batch, "paged_decode_qkv: batch exceeds the workspace")
+    if out is None:
+        out = torch.empty((b, hq * 128), dtype=BF16, device=qkv.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_paged_decode_qkv(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
+                                        _ptr(q_weight), _ptr(k_weight), float(eps), _ptr(k_cache), _ptr(v_cache), k_cache.shape[-3],
+                                        _ptr(kv_indices), _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv, float(sm_scale),
+                                        _stream()), "nvx_paged_decode_qkv")
+    return out
 
 
 def paged_decode(q, k_cache, v_cache, kv_indices, batch: int, ws: DecodeWorkspace, sm_scale, out=None):

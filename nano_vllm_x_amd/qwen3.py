@@ -137,9 +137,15 @@ class Qwen3Attention(nn.Module):
         if fused and md.forward_mode == ForwardMode.DECODE:
             qkv = decode_linear(hidden_states, self.qkv_proj.weight, "qkv")
             k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
-            q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
-                                      md.output_kv_indices, k_cache, v_cache, self.num_heads, self.num_kv_heads)
-            out = decode_linear(self.attn(q, None, None), self.o_proj.weight, "o")
+            if getattr(md.wrapper, "qkv_fused", False):   # norm + rotary + scatter happen inside the attention kernel
+                md.wrapper._sm_scale = self.attn.scaling
+                attn_out = md.wrapper.run_qkv(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
+                                              (k_cache, v_cache))
+            else:
+                q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
+                                          md.output_kv_indices, k_cache, v_cache, self.num_heads, self.num_kv_heads)
+                attn_out = self.attn(q, None, None)
+            out = decode_linear(attn_out, self.o_proj.weight, "o")
             return out if out.dtype == torch.float32 else tpd.tp_all_reduce(out)
         qkv = self.qkv_proj(hidden_states)
         if fused:

@@ -491,3 +491,44 @@ def test_linear_decode_rejects_bad_shapes(ops):
     with pytest.raises(RuntimeError, match="512, 768 or 1024"):
         ops.linear_decode(x[:4], w)
     assert ops.linear_decode_splits(64, 96) == 0
+
+
+# -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (2, 1), (8, 2), (8, 1)])
+def test_decode_attention_from_raw_qkv_matches_the_two_kernel_path(ops, hq, hkv):
+    """nvx_paged_decode_qkv == nvx_qknorm_rope_store followed by nvx_paged_decode: the pool rows it
+    writes are bit-identical, the attention output agrees to the decode tolerance (the new token joins
+    the running softmax at another point of the sum)."""
+    gen = torch.Generator().manual_seed(31 + hq)
+    lens = [1, 2, 17, 128, 129, 300, 1500]          # includes the new token
+    b, total = len(lens), sum(lens)
+    slots = 2 * total + 64
+    kc, vc = _random_cache(gen, slots, hkv)
+    perm = torch.randperm(slots - 1, generator=gen)[:total].to(torch.int32) + 1
+    indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    new_slots = torch.tensor([int(perm[indptr[i + 1] - 1]) for i in range(b)], dtype=torch.int64)
+    new_slots[3] = -1                                # a padding-style row: nothing stored, pool row read instead
+    qkv = torch.randn(b, (hq + 2 * hkv) * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int64, device=DEV)
+    from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+    table = build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(torch.bfloat16).to(DEV)
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(torch.bfloat16).to(DEV)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    kv_start = torch.from_numpy(indptr[:-1]).to(DEV)
+    idx = perm.to(DEV)
+    ns = new_slots.to(DEV)
+
+    kc1, vc1 = kc.clone().to(DEV), vc.clone().to(DEV)
+    ws1 = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    q = ops.qknorm_rope_store(qkv, pos, table, qw, kw, 1e-6, ns, kc1, vc1, hq, hkv)
+    ops.decode_plan(kv_len, kv_start, ws1)
+    want = ops.paged_decode(q, kc1, vc1, idx, b, ws1, 128 ** -0.5)
+
+    kc2, vc2 = kc.clone().to(DEV), vc.clone().to(DEV)
+    ws2 = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    ops.decode_plan(kv_len, kv_start, ws2, out_slots=ns)
+    got = ops.paged_decode_qkv(qkv, pos, table, qw, kw, 1e-6, kc2, vc2, idx, b, ws2, 128 ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    attn_close(got.view(b, hq, 128), want.view(b, hq, 128).float())

@@ -88,11 +88,24 @@ def cmd_decode(args):
         idx = torch.from_numpy(flat).to(DEV)
         q = torch.randn(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
         out = torch.empty_like(q)
-        ops.decode_plan(kv_len, kv_start, ws)
+        if args.qkv:   # the variant fed with the raw fused projection (norm + rotary + scatter inside)
+            from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+            qkv = torch.randn(b, (HQ + 2 * HKV) * 128, device=DEV, dtype=torch.bfloat16)
+            pos = (kv_len - 1).to(torch.int64)
+            new_slots = idx[(kv_start + kv_len - 1)].to(torch.int64)
+            table = build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+            nw = torch.ones(128, device=DEV, dtype=torch.bfloat16)
+            ops.decode_plan(kv_len, kv_start, ws, out_slots=new_slots)
 
-        def run():
-            ops.paged_decode(q, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
-            layer[0] = (layer[0] + 1) % LAYERS
+            def run():
+                ops.paged_decode_qkv(qkv, pos, table, nw, nw, 1e-6, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
+                layer[0] = (layer[0] + 1) % LAYERS
+        else:
+            ops.decode_plan(kv_len, kv_start, ws)
+
+            def run():
+                ops.paged_decode(q, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
+                layer[0] = (layer[0] + 1) % LAYERS
 
         t = timed(run, args.reps)
         rows = int(lens.sum())
@@ -197,5 +210,6 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--hkv1", action="store_true")
+    ap.add_argument("--qkv", action="store_true")
     a = ap.parse_args()
     {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "linear": cmd_linear}[a.cmd](a)
