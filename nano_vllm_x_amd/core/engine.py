@@ -83,16 +83,40 @@ class Engine(EngineCore):
         self.model_runner.initialize_kv_cache(kv_cache_size)
         super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len, prefix_reuse=prefix_reuse)
         self.scheduler.on_release = self.model_runner.release_sequence
+        self._inflight = None
 
     def step(self) -> list:
+        if self._inflight is None and not self.begin_step():
+            return []
+        return self.end_step()
+
+    # The two halves of a step, for a driver that wants the host free while the device works
+    # (LLM._run_engine hands out the previous step's tokens between them).
+    def begin_step(self) -> bool:
+        """Schedule a batch and queue it on the device.  False if there is nothing to run."""
+        assert self._inflight is None
         batch = self.scheduler.schedule()
         if not batch:
+            return False
+        self._inflight = self.model_runner.launch_step(batch)
+        return True
+
+    def end_step(self) -> list:
+        """Wait for the step in flight and fold its tokens into the sequences."""
+        handle, self._inflight = self._inflight, None
+        if handle is None:
             return []
-        output_ids = self.model_runner.execute_model(batch)
-        return self.update_from_output(batch, output_ids)
+        return self.update_from_output(handle[0], self.model_runner.finish_step(handle))
+
+    @property
+    def step_in_flight(self) -> bool:
+        return self._inflight is not None
 
     def reset(self):
         """Forget every sequence and every cached prefix (fresh scheduler, same pool and graphs)."""
+        if self._inflight is not None:
+            self.model_runner.finish_step(self._inflight)
+            self._inflight = None
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
         self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse)

@@ -13,9 +13,8 @@ What differs, by design, on MI355X:
 """
 from __future__ import annotations
 
-import time
-
 import gc
+import time
 from typing import Optional
 
 import numpy as np
@@ -55,6 +54,7 @@ class ModelRunner:
         self._config_override = config
         self.graph: Optional[HIPGraph] = None
         self.block_table: Optional[BlockTable] = None
+        self._sp_key, self._sp_dev = None, None
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
 
     # -- set-up -----------------------------------------------------------------------------------
@@ -119,7 +119,11 @@ class ModelRunner:
 
     def prepare_sampling_params(self, batch: ForwardBatch):
         """One (4, B) fp32 upload: temperature, min_p, top_p, top_k (-1 -> vocabulary size,
-        model_runner.py:202-206).  Returns the four per-row device tensors."""
+        model_runner.py:202-206).  Returns the four per-row device tensors.  A sequence's parameters never
+        change, so the upload is skipped while the batch holds the same sequences as the step before."""
+        key = tuple(s.seq_id for s in batch.seqs)
+        if key == self._sp_key:
+            return self._sp_dev
         v = self.hf_config.vocab_size
         n = batch.num_seqs
         host = np.empty((4, n), dtype=np.float32)
@@ -128,7 +132,8 @@ class ModelRunner:
             host[0, i], host[1, i], host[2, i] = sp.temperature, sp.min_p, sp.top_p
             host[3, i] = v if sp.top_k == -1 else min(sp.top_k, v)
         dev = torch.from_numpy(host).to(self.device, non_blocking=True)
-        return dev[0], dev[1], dev[2], dev[3].to(torch.int64)
+        self._sp_key, self._sp_dev = key, (dev[0], dev[1], dev[2], dev[3].to(torch.int64))
+        return self._sp_dev
 
     @staticmethod
     def prepare_last_hidden_states(batch: ForwardBatch, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -156,16 +161,16 @@ class ModelRunner:
 
     @torch.inference_mode()
     def execute_model(self, batch: ForwardBatch) -> list:
-        if batch.num_seqs == 0:
-            return []
-        t0 = time.perf_counter()
-        try:
-            return self._execute_model(batch)
-        finally:   # the step ends with a stream synchronisation, so host wall time is step time
-            key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
-            self.stats[key] = self.stats.get(key, 0.0) + (time.perf_counter() - t0)
+        return self.finish_step(self.launch_step(batch))
 
-    def _execute_model(self, batch: ForwardBatch) -> list:
+    @torch.inference_mode()
+    def launch_step(self, batch: ForwardBatch):
+        """Queue one step on the device (forward, sampling, copy of the sampled ids to pinned memory)
+        and return without waiting for it; finish_step() collects the ids.  Between the two the host is
+        free (the engine hands the previous step's tokens to their consumers there)."""
+        if batch.num_seqs == 0:
+            return None
+        t0 = time.perf_counter()
         logits = self.compute_logits(batch)
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
@@ -173,9 +178,22 @@ class ModelRunner:
         tpd.tp_broadcast(ids, src=0)
         if n <= self.max_bs:
             self._sample_host[:n].copy_(ids, non_blocking=True)
+            ids = None
+        return (batch, ids, t0)
+
+    def finish_step(self, handle) -> list:
+        if handle is None:
+            return []
+        batch, ids, t0 = handle
+        n = batch.num_seqs
+        if ids is None:
             torch.cuda.current_stream().synchronize()
-            return self._sample_host[:n].tolist()
-        return ids.tolist()
+            out = self._sample_host[:n].tolist()
+        else:
+            out = ids.tolist()
+        key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
+        self.stats[key] = self.stats.get(key, 0.0) + (time.perf_counter() - t0)   # launch to completion
+        return out
 
     def _execute_model_eager(self, batch: ForwardBatch) -> torch.Tensor:
         input_ids, positions = self.prepare_input(batch)

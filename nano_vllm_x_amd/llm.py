@@ -70,8 +70,13 @@ class LLM:
         has already queued its sequence, so a burst of requests is admitted as one prefill batch."""
         eng = self.engine
         try:
-            while eng.has_unfinished_sequences():
-                for out in eng.step():
+            while eng.has_unfinished_sequences() or eng.step_in_flight:
+                outs = eng.step()          # waits for the step in flight (or runs one)
+                # the next step goes to the device before this one's tokens are handed out: queue wake-ups,
+                # detokenisation and the consumers' own code then run while the device is busy
+                if eng.has_unfinished_sequences():
+                    eng.begin_step()
+                for out in outs:
                     q = self.request_states.get(out.seq_id)
                     if q is None:
                         continue
