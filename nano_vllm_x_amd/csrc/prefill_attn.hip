@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
     int kmax = qb * QPOS + QPOS + offset;       // keys visible to the workgroup's last query
     kmax = kmax > lkv ? lkv : kmax;
     const int wave_last_key = qb * QPOS + pb * 32 + 31 + offset;  // last key any query of this wave sees
+    const int wave_first_vis = qb * QPOS + pb * 32 + offset;      // last key the wave's FIRST query sees
     const int n_tiles = (kmax + PF_KVBLK - 1) / PF_KVBLK;
     const int64_t row_elems = (int64_t)hkv * 128;
 
@@ -205,21 +206,27 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
             }
         }
         // ---- mask, online softmax (this lane: one query, 32 of the tile's 64 keys) ----
+        // Scores stay unscaled; the scale rides on the fused multiply-add inside the exponent.  Only
+        // tiles that cross the causal diagonal (or the end of the sequence) pay for the mask.
         const int vis = q_ok ? qi + offset : -1;   // last visible key index of this lane's query
+        if (key_base + PF_KVBLK - 1 > wave_first_vis) {   // wave-uniform
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    st[kb][r] = key <= vis ? st[kb][r] : -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float s = key <= vis ? st[kb][r] * scale_log2 : -INFINITY;
-                st[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = fmaxf(m_run, mx * scale_log2);     // scale_log2 > 0
         const float mref = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - mref);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
         m_run = m_new;
         l_run *= alpha;
         if (!__all(alpha == 1.0f)) {
@@ -236,8 +243,8 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float p0 = exp2f(st[kb][8 * s2 + 2 * j] - mref);
-                    const float p1 = exp2f(st[kb][8 * s2 + 2 * j + 1] - mref);
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j], scale_log2, -mref));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j + 1], scale_log2, -mref));
                     l_run += p0 + p1;
                     w[j] = pack_bf16x2(p0, p1);
                 }
@@ -310,7 +317,7 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
     } while (0)
     switch (g) {
         case 1: NVX_PF(1, 4, 128); break;
-        case 2: NVX_PF(2, 4, 64); break;
+        case 2: NVX_PF(2, 8, 128); break;
         case 4: NVX_PF(4, 4, 32); break;
         case 8: NVX_PF(8, 8, 32); break;
         default: return nvx_fail(NVX_EUNSUPPORTED, "nvx_paged_prefill: query/kv head ratio %d not in {1,2,4,8}", g);
