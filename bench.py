@@ -11,9 +11,10 @@ are reported (`value` = nominal, `generated_tokens_per_s` = real).
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, TP = N)
 
 Also in the JSON line:
-  roofline      -- the dominant hand-written kernel (paged decode attention), replayed on the decode
-                   batches of this workload with HIP events on the launch stream; algorithmic bytes =
-                   kv_rows * 2 (K,V) * kv_heads * 128 * 2 B + q/o rows + 4 B per block-table entry.
+  roofline      -- the dominant hand-written kernel (paged decode attention, the variant the engine's
+                   captured steps launch), replayed on the decode batches of this workload with HIP
+                   events on the launch stream; algorithmic bytes = kv_rows * 2 (K,V) * kv_heads * 128 *
+                   2 B + raw projection rows in + output rows + 4 B per block-table entry.
   cpu_baseline  -- the CPU oracle engine (oracle/, a port of the same path) on a bounded sample of the
                    same workload, timed on this box's host cores (rank 0, N = 1 only).
 """
@@ -93,15 +94,18 @@ def decode_batches_of_workload(prompts, max_tokens, kv_size, max_bs, context_len
 
 
 def decode_attention_roofline(runner, batches, reps: int = 14):
-    """Time nvx_paged_decode (+ its merge kernel) on the kept decode batches with HIP events on the
-    stream the kernels are launched on (torch's current stream).  Consecutive launches use different
-    layers of the real KV pool so that no launch finds its rows in the Infinity Cache."""
+    """Time the decode-attention launch the engine's captured steps use -- nvx_paged_decode_qkv: q/k norm +
+    rotary + scatter of the new row + attention, followed by its merge kernel -- on the kept decode
+    batches, with HIP events on the stream the kernels are launched on.  Consecutive launches use
+    different layers of the real KV pool so that no launch finds its rows in the Infinity Cache."""
     from nano_vllm_x_amd import ops
 
     dev = runner.device
     hq, hkv, layers = runner.num_heads, runner.num_kv_heads, runner.num_layers
     ws = ops.DecodeWorkspace(runner.max_bs, hq, hkv, dev)
     kc, vc = runner.kv_cache.k_cache, runner.kv_cache.v_cache
+    table = runner.model.model.rope_table
+    norm_w = torch.ones(128, device=dev, dtype=torch.bfloat16)
     total_bytes = total_ms = 0.0
     launches = 0
     layer = 0
@@ -110,18 +114,23 @@ def decode_attention_roofline(runner, batches, reps: int = 14):
         kv_len = torch.from_numpy(lens).to(dev)
         kv_start = torch.from_numpy(np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.int64)).to(dev)
         idx = torch.from_numpy(flat).to(dev)
-        q = torch.randn(b, hq * 128, device=dev, dtype=torch.bfloat16)
-        out = torch.empty_like(q)
-        ops.decode_plan(kv_len, kv_start, ws)
+        qkv = torch.randn(b, (hq + 2 * hkv) * 128, device=dev, dtype=torch.bfloat16)
+        pos = (kv_len - 1).to(torch.int64)
+        new_slots = idx[kv_start + kv_len.to(torch.int64) - 1].to(torch.int64)   # the last listed slot takes the new row
+        out = torch.empty(b, hq * 128, device=dev, dtype=torch.bfloat16)
+        ops.decode_plan(kv_len, kv_start, ws, out_slots=new_slots)
         rows = int(lens.sum())
-        alg = rows * 2 * hkv * 128 * 2 + 2 * b * hq * 128 * 2 + 4 * rows
+        # K and V rows of every listed token (the new one is written instead of read: same bytes), the raw
+        # projection in, the attention output out, one block-table entry per token
+        alg = rows * 2 * hkv * 128 * 2 + b * (hq + 2 * hkv) * 128 * 2 + b * hq * 128 * 2 + 4 * rows
+
         # `reps` launches over consecutive layers are captured into one hipGraph and the replay is timed
         # with HIP events on the replay stream: launched one by one from Python, a 30-microsecond kernel
         # pair would be paced by the host's launch rate, not by the GPU
         def launch_all():
             nonlocal layer
             for _ in range(reps):
-                ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
+                ops.paged_decode_qkv(qkv, pos, table, norm_w, norm_w, 1e-6, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
                 layer = (layer + 1) % layers
 
         launch_all()
@@ -146,7 +155,7 @@ def decode_attention_roofline(runner, batches, reps: int = 14):
     achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("paged_decode_kernel"),
-            "kernel": "paged_decode_kernel (+decode_merge_kernel)", "launches": launches,
+            "kernel": "paged_decode_kernel<2,2,true> (nvx_paged_decode_qkv) + decode_merge_kernel", "launches": launches,
             "avg_launch_us": round(total_ms * 1e3 / max(1, launches), 2),
             "avg_algorithmic_bytes": int(total_bytes / max(1, launches))}
 

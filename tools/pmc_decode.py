@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One launch of paged decode attention per sampled decode batch of the bench workload, plus a
+"""One launch of paged decode attention (the variant fed with the raw projection) per sampled decode batch of the bench workload, plus a
 calibration copy of known size, for `rocprofv3 --pmc <counter> -- python3 tools/pmc_decode.py`.
 
 Prints the algorithmic bytes of the sampled launches so that tools/pmc_summarise.py can set the
@@ -33,6 +33,9 @@ def main():
     kc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
     vc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
     ws = ops.DecodeWorkspace(256, HQ, HKV, DEV)
+    from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+    table = build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    norm_w = torch.ones(128, device=DEV, dtype=torch.bfloat16)
     # calibration: a 1 GiB device-to-device copy (reads 1 GiB, writes 1 GiB) through a wide elementwise kernel
     cal = torch.empty(1 << 28, dtype=torch.float32, device=DEV).normal_()
     cal2 = torch.empty_like(cal)
@@ -46,13 +49,15 @@ def main():
         kv_len = torch.from_numpy(lens).to(DEV)
         kv_start = torch.from_numpy(np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.int64)).to(DEV)
         idx = torch.from_numpy(flat).to(DEV)
-        q = torch.randn(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
-        out = torch.empty_like(q)
-        ops.decode_plan(kv_len, kv_start, ws)
-        ops.paged_decode(q, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
+        qkv = torch.randn(b, (HQ + 2 * HKV) * 128, device=DEV, dtype=torch.bfloat16)
+        out = torch.empty(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
+        pos = (kv_len - 1).to(torch.int64)
+        new_slots = idx[kv_start + kv_len.to(torch.int64) - 1].to(torch.int64)
+        ops.decode_plan(kv_len, kv_start, ws, out_slots=new_slots)
+        ops.paged_decode_qkv(qkv, pos, table, norm_w, norm_w, 1e-6, kc[layer], vc[layer], idx, b, ws, 128 ** -0.5, out=out)
         layer = (layer + 1) % LAYERS
         rows = int(lens.sum())
-        alg.append(rows * 2 * HKV * 128 * 2 + 2 * b * HQ * 128 * 2 + 4 * rows)
+        alg.append(rows * 2 * HKV * 128 * 2 + b * (HQ + 2 * HKV) * 128 * 2 + b * HQ * 128 * 2 + 4 * rows)
     torch.cuda.synchronize()
     info = {"launches": len(alg), "avg_algorithmic_bytes": sum(alg) / len(alg), "calibration_bytes_each_way": cal.numel() * 4}
     print(json.dumps(info))
