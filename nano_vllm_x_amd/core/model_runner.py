@@ -14,6 +14,7 @@ What differs, by design, on MI355X:
 from __future__ import annotations
 
 import gc
+import sys
 import time
 from typing import Optional
 
@@ -108,7 +109,18 @@ class ModelRunner:
         self._sample_host = torch.zeros(self.max_bs, dtype=torch.int64, pin_memory=True)
         if not self.enforce_eager:
             self.graph = HIPGraph()
-            self.capture_graph()
+            try:
+                self.capture_graph()
+            except RuntimeError as e:
+                if self.tp_size == 1:
+                    raise
+                # a collective that cannot be captured on this RCCL build: every rank hits the same error at
+                # the same point, so all fall back together to eager decode steps (same kernels, launched
+                # one by one)
+                print(f"[nano_vllm_x_amd] rank {self.rank}: decode graph capture failed ({e}); running decode eagerly",
+                      file=sys.stderr, flush=True)
+                self.graph = None
+                torch.cuda.synchronize()
 
     # -- per-step host preparation -------------------------------------------------------------------
     def prepare_input(self, batch: ForwardBatch):

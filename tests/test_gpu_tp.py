@@ -1,0 +1,99 @@
+"""Tensor parallelism on the device path: two ranks sharing the one GPU of the test box.
+
+RCCL refuses two ranks on one device, so the ranks talk through gloo (device tensors are staged through
+the host) and decode runs eagerly; what is checked is everything tensor parallelism changes on the
+device side: per-rank head counts in the attention / norm / rotary / scatter kernels, column- and
+row-sharded projections (skinny kernel and library GEMM), vocab-parallel embedding, the LM-head gather
+and the broadcast of the sampled ids.  The logits of the two-rank model must equal the one-rank model's
+to bf16 working precision (the all-reduce sums two bf16 halves instead of one fp32 accumulation).
+"""
+from __future__ import annotations
+
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(vocab_size=1000, hidden_size=512, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=8,
+           num_key_value_heads=2, head_dim=128, max_position_embeddings=256, tie_word_embeddings=False)
+PROMPT_LENS = (5, 19, 33, 8)
+
+
+def _run_model(tp: int, rank: int, port: int):
+    from nano_vllm_x_amd import distributed as tpd
+    from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, SamplingParams, Sequence
+    from nano_vllm_x_amd.core.model_runner import ModelRunner
+    from nano_vllm_x_amd.qwen3 import Qwen3Config
+
+    if tp > 1:
+        tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port)
+    r = ModelRunner(model="tp-test", max_bs=8, tp_size=tp, enforce_eager=True, context_len=128,
+                    config=Qwen3Config.from_dict(CFG), seed=5)
+    r.load_model()           # seeded random weights: every rank draws the full matrices and keeps its shard
+    r.initialize_kv_cache(512)
+    rng = np.random.default_rng(9)
+    seqs, slot = [], 0
+    for i, n in enumerate(PROMPT_LENS):
+        p = rng.integers(0, CFG["vocab_size"], size=n).tolist()
+        seqs.append(Sequence(seq_id=f"s{i}", token_ids=p, num_tokens=n, prompt_len=n, kv_indices=list(range(slot, slot + n)),
+                             sampling_params=SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=8)))
+        slot += n + 8
+    logits, sampled = [], []
+    for step in range(3):
+        mode = ForwardMode.PREFILL if step == 0 else ForwardMode.DECODE
+        batch = ForwardBatch(forward_mode=mode, num_seqs=len(seqs), seqs=seqs)
+        logits.append(r.compute_logits(batch).float().cpu().numpy())
+        sampled.append(r.execute_model(batch) if step == 2 else None)    # the sampler + broadcast path, once
+        for s in seqs:
+            s.cached_kv_len = len(s.kv_indices)
+            s.token_ids.append(int(rng.integers(0, CFG["vocab_size"])))
+            s.kv_indices.append(s.kv_indices[-1] + 1)
+    heads = (r.num_heads, r.num_kv_heads)
+    r.shutdown()
+    return logits, sampled[2], heads
+
+
+def _worker(rank, port, q):
+    try:
+        out = _run_model(2, rank, port)
+        q.put((rank, out, None))
+    except Exception:   # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_two_ranks_on_one_gpu_match_one_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        rank, out, err = q.get(timeout=240)
+        assert err is None, f"rank {rank} failed:\n{err}"
+        results[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+    want, want_ids, heads1 = _run_model(1, 0, 0)
+    assert heads1 == (8, 2) and results[0][2] == (4, 1)
+    for step in range(3):
+        a0, a1, b = results[0][0][step], results[1][0][step], want[step]
+        assert np.array_equal(a0, a1), "ranks disagree after the LM-head gather"
+        tol = 2.0 ** -6 * np.abs(b).max()
+        assert np.abs(a0 - b).max() <= tol, (step, np.abs(a0 - b).max(), tol)
+        assert (a0.argmax(-1) == b.argmax(-1)).all()
+    assert results[0][1] == results[1][1] == want_ids      # greedy ids, broadcast from rank 0
