@@ -220,8 +220,9 @@ def main():
     t_init = time.perf_counter()
     kv_size = args.kv_cache_size or None
     if kv_size is None and world > 1:
-        # per-rank KV bytes shrink with TP; keep the slot count a host can index (a few million)
-        kv_size = 4_000_000
+        # per-rank KV bytes shrink with TP; keep the slot count of the one-GPU run (0.8 of 288 GB at
+        # 114 688 B per token) instead of letting it grow with the number of ranks
+        kv_size = 2_000_000
     llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
               context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size)
     init_s = time.perf_counter() - t_init
