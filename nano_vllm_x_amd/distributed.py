@@ -27,7 +27,9 @@ def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | N
         _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
         return 0
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # NVX_TP_BACKEND=gloo lets several ranks share one GPU (rehearsals on a one-GPU box: RCCL refuses
+        # two ranks on one device); collectives then stage through the host and cannot be graph-captured
+        backend = os.environ.get("NVX_TP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         if rank is None:
             rank = int(os.environ.get("RANK", "0"))
@@ -56,9 +58,21 @@ def tp_size() -> int:
     return _TP_SIZE
 
 
+def _via_host(x: torch.Tensor) -> bool:
+    """gloo with device tensors (ranks sharing one GPU in tests and rehearsals): its own device staging
+    was seen to hang intermittently with two processes on one GPU, so the tensor is staged through the
+    host here, synchronously.  RCCL never takes this path."""
+    return x.is_cuda and dist.get_backend(_TP_GROUP) == "gloo"
+
+
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     if _TP_SIZE > 1:
-        dist.all_reduce(x, group=_TP_GROUP)
+        if _via_host(x):
+            h = x.float().cpu() if x.dtype == torch.bfloat16 else x.cpu()
+            dist.all_reduce(h, group=_TP_GROUP)
+            x.copy_(h)
+        else:
+            dist.all_reduce(x, group=_TP_GROUP)
     return x
 
 
@@ -67,15 +81,25 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     if _TP_SIZE == 1:
         return x
     x = x.contiguous()
-    flat = torch.empty(_TP_SIZE * x.numel(), dtype=x.dtype, device=x.device)   # rank-major concatenation
-    dist.all_gather_into_tensor(flat, x.view(-1), group=_TP_GROUP)
+    if _via_host(x):
+        h = torch.empty(_TP_SIZE * x.numel(), dtype=x.dtype)
+        dist.all_gather_into_tensor(h, x.view(-1).cpu(), group=_TP_GROUP)
+        flat = h.to(x.device)
+    else:
+        flat = torch.empty(_TP_SIZE * x.numel(), dtype=x.dtype, device=x.device)   # rank-major concatenation
+        dist.all_gather_into_tensor(flat, x.view(-1), group=_TP_GROUP)
     out = flat.view((_TP_SIZE,) + tuple(x.shape))
     return out.movedim(0, -2).reshape(x.shape[:-1] + (_TP_SIZE * x.shape[-1],))
 
 
 def tp_broadcast(x: torch.Tensor, src: int = 0) -> torch.Tensor:
     if _TP_SIZE > 1:
-        dist.broadcast(x, src=src, group=_TP_GROUP)
+        if _via_host(x):
+            h = x.cpu()
+            dist.broadcast(h, src=src, group=_TP_GROUP)
+            x.copy_(h)
+        else:
+            dist.broadcast(x, src=src, group=_TP_GROUP)
     return x
 
 
@@ -83,7 +107,7 @@ def tp_all_gather_min_int(value: int, device) -> int:
     """Smallest `value` over the ranks (KV pool sizing, model_runner.py:166-169)."""
     if _TP_SIZE == 1:
         return value
-    t = torch.tensor([value], dtype=torch.int64, device=device)
+    t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend(_TP_GROUP) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_TP_GROUP)
     return int(t.item())
 

@@ -92,6 +92,11 @@ class LLM:
                         q.put_nowait(GenerateOutput(token_str=text, is_finished=False, finish_reason=None,
                                                     num_prompt_tokens=0, num_generated_tokens=0, token_id=out.new_token_id))
                 await asyncio.sleep(0)   # let consumers drain and new requests arrive
+        except Exception as e:   # noqa: BLE001 - a dead pump must not leave its consumers waiting forever
+            for q in list(self.request_states.values()):
+                q.put_nowait(e)
+            self.request_states.clear()
+            raise
         finally:
             self._pump = None
 
@@ -119,6 +124,8 @@ class LLM:
                 out = await q.get()
                 if out is None:
                     break
+                if isinstance(out, BaseException):
+                    raise RuntimeError(f"engine step failed: {out}") from out
                 yield out
         except asyncio.CancelledError:
             self.abort(sequence_id)
