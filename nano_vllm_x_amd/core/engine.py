@@ -52,14 +52,13 @@ class EngineCore:
     def update_from_output(self, batch: ForwardBatch, output_ids: list) -> list:
         outs = []
         sched = self.scheduler
+        update, finished, finish = sched.update_sequence, self._is_sequence_finished, sched.finish_sequence
         for seq, tok in zip(batch.seqs, output_ids):
-            sched.update_sequence(seq, tok)
-            done, why = self._is_sequence_finished(seq)
+            update(seq, tok)
+            done, why = finished(seq)
             if done:
-                sched.finish_sequence(seq)
-            outs.append(EngineOutput(seq_id=seq.seq_id, new_token_id=tok, is_finished=done, finish_reason=why,
-                                     num_prompt_tokens=seq.prompt_len,
-                                     num_generated_tokens=seq.num_tokens - seq.prompt_len))
+                finish(seq)
+            outs.append(EngineOutput(seq.seq_id, tok, done, why, seq.prompt_len, seq.num_tokens - seq.prompt_len))
         return outs
 
 

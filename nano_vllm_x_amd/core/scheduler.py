@@ -108,8 +108,20 @@ class Scheduler:
 
     def _extend_running(self):
         """One more slot for every running sequence not already in flight (scheduler.py:82-115)."""
-        picked, passed = [], []
         running = self.running
+        # Steady state (every running sequence fits in one batch, none is in flight, the pool has a slot
+        # for each): one allocator call for the whole batch.  The slots come off the stack in the same
+        # order as one call per sequence would take them, so the assignment is the reference's.
+        if running and len(running) <= self.max_bs and not self.scheduled:
+            need = [s for s in running if len(s.token_ids) > len(s.kv_indices)]
+            if all(len(s.token_ids) - len(s.kv_indices) == 1 for s in need):
+                got = self.kv_manager.kv_cache_allocator.alloc(len(need))
+                if got is not None:
+                    for s, slot in zip(need, got):
+                        s.kv_indices.append(slot)
+                    self.scheduled.update(s.seq_id for s in running)
+                    return list(running)
+        picked, passed = [], []
         while running and len(picked) < self.max_bs:
             seq = running.popleft()
             passed.append(seq)
