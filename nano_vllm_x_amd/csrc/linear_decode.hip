@@ -37,11 +37,12 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     int k_total) {
     constexpr int HALVES = MODE == 1 ? 2 : 1;
     constexpr int STEPS = KC / 32;               // MFMA k-steps per tile
-    constexpr int GROUP = 8;                     // k-steps per prefetch group
-    constexpr int GPT = STEPS / GROUP;           // groups per tile
+    constexpr int GPT = (MODE == 1 && KC == 1024) ? 4 : 2;   // prefetch groups per tile (register budget)
+    constexpr int GROUP = STEPS / GPT;           // k-steps per group: a whole tile's fragments are in flight
     constexpr int PIECES_ROW = KC / 8;           // 16-byte pieces per W row
     constexpr int PIECES_HALF = 16 * PIECES_ROW;
     constexpr int WLOADS = HALVES * PIECES_HALF / LIN_THREADS;   // pieces per thread, all in flight at once
+    static_assert(GROUP % 2 == 0, "k-steps are permuted in pairs");
     static_assert(KC % 256 == 0, "K slice must be a multiple of 256");
     __shared__ nvx_u32x4 lds[HALVES * STEPS * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -59,9 +60,12 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
         const int tile = wave + LIN_WAVES * (item / GPT), group = item % GPT;
         int row = tile * 16 + l16;
         row = row < m_rows ? row : m_rows - 1;
-        const uint16_t* p = x + (int64_t)row * x_stride + k0 + group * (GROUP * 32) + quad * 8;
+        // k order within a pair of k-steps is permuted so that the four lane quads of two consecutive
+        // loads cover one whole 128-byte line of the row (quad q: bytes 32q..32q+15, then 32q+16..32q+31)
+        // instead of half of two lines; W is parked in LDS in the same order
+        const uint16_t* p = x + (int64_t)row * x_stride + k0 + group * (GROUP * 32) + quad * 16;
 #pragma unroll
-        for (int i = 0; i < GROUP; ++i) dst[i] = *reinterpret_cast<const nvx_u32x4*>(p + i * 32);
+        for (int i = 0; i < GROUP; ++i) dst[i] = *reinterpret_cast<const nvx_u32x4*>(p + (i >> 1) * 64 + (i & 1) * 8);
     };
     if (n_items > 0) load_b(b_even, 0);
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
             const int p = u * LIN_THREADS + tid;
             const int h = p / PIECES_HALF, ph = p % PIECES_HALF;
             const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
-            lds[h * STEPS * 64 + lin_slot(kp >> 2, kp & 3, r)] = v[u];
+            lds[h * STEPS * 64 + lin_slot(2 * (kp >> 3) + (kp & 1), (kp >> 1) & 3, r)] = v[u];   // piece kp -> (k-step, quad)
         }
     }
     __syncthreads();
