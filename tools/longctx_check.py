@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Long-context serving check (SURVEY config 5 shape on one GPU): context 4096, max_bs 256, prompts
+"""Long-context serving check on one GPU: context 4096, max_bs 256, prompts
 U[1024,3072], U[64,256] new tokens; a KV pool small enough that admission has to wait for running
 sequences.  Prints one JSON line; fails loudly if any request ends with the wrong token count."""
 import asyncio, json, os, random, sys, time
