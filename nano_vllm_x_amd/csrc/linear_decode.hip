@@ -31,20 +31,28 @@ __device__ __forceinline__ int lin_slot(int j, int q, int r) { return j * 64 + q
 // MODE 2: fp32 partials (k_splits, M, N).
 // KC = the K slice of one workgroup (compile time, so that every loop below is straight-line code:
 // with per-element bounds checks the compiler serialises each load behind a full wait).
-template <int MODE, int KC>
+// STAGED = false: activation fragments are loaded straight from global memory in MFMA operand order:
+//   shortest dependent chain, but every load instruction is 64 separate 16-byte requests (16 rows x 4
+//   k pieces), which the address unit serves at about one per clock, so the time grows with the number
+//   of activation rows (~0.045 us per row).
+// STAGED = true: each wave loads its rows coalesced (32 lanes x 16 B = 512 contiguous bytes per row),
+//   parks them in a private 8 KB LDS area (pieces XOR-swizzled by row) and reads the fragments from
+//   there: one more LDS hop per 256 k, a quarter of the address-unit work.  Used above 48 rows.
+template <int MODE, int KC, bool STAGED>
 __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* __restrict__ w, void* __restrict__ y, int m_rows, int n_rows,
     int k_total) {
     constexpr int HALVES = MODE == 1 ? 2 : 1;
     constexpr int STEPS = KC / 32;               // MFMA k-steps per tile
-    constexpr int GPT = (MODE == 1 && KC == 1024) ? 4 : 2;   // prefetch groups per tile (register budget)
-    constexpr int GROUP = STEPS / GPT;           // k-steps per group: a whole tile's fragments are in flight
+    constexpr int GPT = STAGED ? STEPS / 8 : ((MODE == 1 && KC == 1024) ? 4 : 2);   // groups per tile
+    constexpr int GROUP = STEPS / GPT;           // k-steps per group (direct: half a tile in flight; staged: 8 = 256 k)
     constexpr int PIECES_ROW = KC / 8;           // 16-byte pieces per W row
     constexpr int PIECES_HALF = 16 * PIECES_ROW;
     constexpr int WLOADS = HALVES * PIECES_HALF / LIN_THREADS;   // pieces per thread, all in flight at once
     static_assert(GROUP % 2 == 0, "k-steps are permuted in pairs");
     static_assert(KC % 256 == 0, "K slice must be a multiple of 256");
     __shared__ nvx_u32x4 lds[HALVES * STEPS * 64];
+    __shared__ nvx_u32x4 stage[STAGED ? LIN_WAVES * 16 * 32 : 1];   // per wave: 16 rows x 32 pieces of 16 B
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad = lane >> 4, l16 = lane & 15;
     const int n_out = MODE == 1 ? n_rows / 2 : n_rows;
@@ -55,17 +63,27 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     const int tiles = (m_rows + 15) / 16;
     const int my_tiles = tiles > wave ? (tiles - wave + LIN_WAVES - 1) / LIN_WAVES : 0;
     const int n_items = my_tiles * GPT;
-    nvx_u32x4 b_even[GROUP], b_odd[GROUP];
+    nvx_u32x4 b_even[GROUP], b_odd[STAGED ? 1 : GROUP];
     auto load_b = [&](nvx_u32x4 (&dst)[GROUP], int item) {
         const int tile = wave + LIN_WAVES * (item / GPT), group = item % GPT;
-        int row = tile * 16 + l16;
-        row = row < m_rows ? row : m_rows - 1;
-        // k order within a pair of k-steps is permuted so that the four lane quads of two consecutive
-        // loads cover one whole 128-byte line of the row (quad q: bytes 32q..32q+15, then 32q+16..32q+31)
-        // instead of half of two lines; W is parked in LDS in the same order
-        const uint16_t* p = x + (int64_t)row * x_stride + k0 + group * (GROUP * 32) + quad * 16;
+        if constexpr (STAGED) {
+            // load u: rows 2u and 2u+1 of the tile, 32 lanes x 16 B = the 256 k of this group, contiguous
 #pragma unroll
-        for (int i = 0; i < GROUP; ++i) dst[i] = *reinterpret_cast<const nvx_u32x4*>(p + (i >> 1) * 64 + (i & 1) * 8);
+            for (int u = 0; u < 8; ++u) {
+                int row = tile * 16 + 2 * u + (lane >> 5);
+                row = row < m_rows ? row : m_rows - 1;
+                dst[u] = *reinterpret_cast<const nvx_u32x4*>(x + (int64_t)row * x_stride + k0 + group * 256 + (lane & 31) * 8);
+            }
+        } else {
+            int row = tile * 16 + l16;
+            row = row < m_rows ? row : m_rows - 1;
+            // k order within a pair of k-steps is permuted so that the four lane quads of two consecutive
+            // loads cover one whole 128-byte line of the row (quad q: bytes 32q..32q+15, then 32q+16..32q+31)
+            // instead of half of two lines; W is parked in LDS in the same order
+            const uint16_t* p = x + (int64_t)row * x_stride + k0 + group * (GROUP * 32) + quad * 16;
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) dst[i] = *reinterpret_cast<const nvx_u32x4*>(p + (i >> 1) * 64 + (i & 1) * 8);
+        }
     };
     if (n_items > 0) load_b(b_even, 0);
 
@@ -91,6 +109,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
 
     // ---- tiles of X ------------------------------------------------------------------------------
     nvx_f32x4 acc[HALVES];
+    nvx_u32x4* my_stage = stage + (STAGED ? wave * (16 * 32) : 0);
     auto compute = [&](const nvx_u32x4 (&bfrag)[GROUP], int item) {
         const int tile = wave + LIN_WAVES * (item / GPT), g = item % GPT;
         if (g == 0) {
@@ -99,9 +118,16 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
         }
 #pragma unroll
         for (int i = 0; i < GROUP; ++i) {
+            nvx_u32x4 b;
+            if constexpr (STAGED) {   // piece of k-step i for quad q in the pair-permuted k order, row l16
+                const int piece = 8 * (i >> 1) + 2 * quad + (i & 1);
+                b = my_stage[l16 * 32 + (piece ^ l16)];
+            } else {
+                b = bfrag[i];
+            }
 #pragma unroll
             for (int h = 0; h < HALVES; ++h)
-                acc[h] = mfma16(lds[h * STEPS * 64 + lin_slot(g * GROUP + i, quad, l16)], bfrag[i], acc[h]);
+                acc[h] = mfma16(lds[h * STEPS * 64 + lin_slot(g * GROUP + i, quad, l16)], b, acc[h]);
         }
         if (g != GPT - 1) return;
         // C layout: this lane holds X row (tile*16 + l16), W rows n0 + 4*quad + 0..3
@@ -126,14 +152,36 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
             *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
         }
     };
-    // the next item's loads go in flight before the current item is multiplied
-    for (int item = 0; item < n_items; item += 2) {
-        if (item + 1 < n_items) load_b(b_odd, item + 1);
-        compute(b_even, item);
-        if (item + 1 >= n_items) break;
-        if (item + 2 < n_items) load_b(b_even, item + 2);
-        compute(b_odd, item + 1);
+    if constexpr (STAGED) {
+        // per item: registers -> this wave's staging area, next item's loads into the freed registers,
+        // fragments back from LDS (a wave's LDS operations complete in order: no barrier needed)
+        for (int item = 0; item < n_items; ++item) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = 2 * u + (lane >> 5);
+                my_stage[r * 32 + ((lane & 31) ^ r)] = b_even[u];
+            }
+            if (item + 1 < n_items) load_b(b_even, item + 1);
+            compute(b_even, item);
+        }
+    } else {
+        // the next item's loads go in flight before the current item is multiplied
+        for (int item = 0; item < n_items; item += 2) {
+            if (item + 1 < n_items) load_b(b_odd, item + 1);
+            compute(b_even, item);
+            if (item + 1 >= n_items) break;
+            if (item + 2 < n_items) load_b(b_even, item + 2);
+            compute(b_odd, item + 1);
+        }
     }
+}
+
+#include <stdlib.h>
+// rows above which the activations go through the LDS staging area (NVX_LIN_STAGED_MIN overrides: tuning)
+static int lin_staged_min_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NVX_LIN_STAGED_MIN"); v = e ? atoi(e) : 48; }
+    return v;
 }
 
 static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
@@ -164,10 +212,13 @@ extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void
     const int kc = (int)(k / k_splits);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(n_out / 16), (unsigned)k_splits);
-#define NVX_LIN(MODE, KC) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
-                                             x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
-#define NVX_LIN_KC(MODE) do { if (kc == 512) NVX_LIN(MODE, 512); else if (kc == 768) NVX_LIN(MODE, 768); else NVX_LIN(MODE, 1024); } while (0)
-    if (mode == 0) NVX_LIN_KC(0); else if (mode == 1) NVX_LIN_KC(1); else NVX_LIN_KC(2);
+    const bool staged = m > lin_staged_min_rows();
+#define NVX_LIN(MODE, KC, ST) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC, ST>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
+                                                 x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
+#define NVX_LIN_KC(MODE, ST) do { if (kc == 512) NVX_LIN(MODE, 512, ST); else if (kc == 768) NVX_LIN(MODE, 768, ST); else NVX_LIN(MODE, 1024, ST); } while (0)
+#define NVX_LIN_ST(MODE) do { if (staged) NVX_LIN_KC(MODE, true); else NVX_LIN_KC(MODE, false); } while (0)
+    if (mode == 0) NVX_LIN_ST(0); else if (mode == 1) NVX_LIN_ST(1); else NVX_LIN_ST(2);
+#undef NVX_LIN_ST
 #undef NVX_LIN_KC
 #undef NVX_LIN
     return nvx_check_launch("nvx_linear_decode");

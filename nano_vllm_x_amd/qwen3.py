@@ -81,7 +81,7 @@ def load_config(model: str) -> Qwen3Config:
 # Largest decode batch for which the skinny projection kernel (ops.linear_decode) beats the library
 # GEMM, per projection; measured on MI355X with the Qwen3-0.6B shapes (tools/kernel_bench.py linear).
 # Above these, and for every prefill, the projection is a library GEMM.
-DECODE_LINEAR_MAX_ROWS = {"qkv": 128, "o": 256, "gate_up": 256, "down": 160}
+DECODE_LINEAR_MAX_ROWS = {"qkv": 176, "o": 256, "gate_up": 256, "down": 256}
 
 
 def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
