@@ -35,9 +35,13 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
     return ctr;
 }
 
+// Gumbel noise from 23 random bits.  (r >> 9) + 0.5 is exact in fp32 (24 significant bits), so u lies
+// strictly inside (0, 1); with 24 bits the top value rounds to u = 1, -log(u) = 0 and the noise becomes
+// +infinity: that token would win whatever its logit.  The inner logarithm is clamped at 2^-25 as well, in
+// case the fast logarithm returns 0 just below 1 (the noise is then at most 17.3).
 __device__ __forceinline__ float gumbel_from_bits(uint32_t r) {
-    const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-    return -__logf(-__logf(u));
+    const float u = ((float)(r >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    return -__logf(fmaxf(-__logf(u), 2.98023224e-8f));
 }
 
 // order-preserving map fp32 -> uint32 (ascending)

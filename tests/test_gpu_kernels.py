@@ -532,3 +532,125 @@ def test_decode_attention_from_raw_qkv_matches_the_two_kernel_path(ops, hq, hkv)
     torch.cuda.synchronize()
     assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
     attn_close(got.view(b, hq, 128), want.view(b, hq, 128).float())
+
+
+# -----------------------------------------------------------------------------------------------
+# Full-size runs, checked through properties that need no CPU oracle at that size.
+def _full_size_decode(ops, perm_seed, lens, hq=16, hkv=8, slots=1_100_000, scale_v=1.0):
+    """Logical K/V content is a function of (sequence, position) only; `perm_seed` picks which physical
+    slots hold it."""
+    b, total = len(lens), int(sum(lens))
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    k_log = torch.randn(total, hkv, 128, generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    v_log = (torch.randn(total, hkv, 128, generator=gen, device=DEV, dtype=torch.float32) * scale_v).to(torch.bfloat16)
+    q = torch.randn(b, hq * 128, generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    pg = torch.Generator().manual_seed(perm_seed)
+    perm = torch.randperm(slots, generator=pg)[:total].to(torch.int32).to(DEV)
+    kc = torch.zeros(slots, hkv, 128, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    kc[perm.long()] = k_log
+    vc[perm.long()] = v_log
+    indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    ws = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    ops.decode_plan(torch.tensor(lens, dtype=torch.int32, device=DEV), torch.from_numpy(indptr[:-1]).to(DEV), ws)
+    out = ops.paged_decode(q, kc, vc, perm, b, ws, 128 ** -0.5)
+    torch.cuda.synchronize()
+    return out.view(b, hq, 128), v_log, indptr
+
+
+def test_decode_full_size_is_invariant_to_slot_placement_and_linear_in_v(ops):
+    """256 sequences x 4096 keys (the largest decode batch the engine's configuration allows: 1 M KV
+    rows per layer): the result may not depend on WHERE the rows live, doubling V must exactly double it
+    (power-of-two scaling commutes with every rounding), and every output lies within the range of the
+    values it averages."""
+    lens = [4096] * 256
+    a, v_log, indptr = _full_size_decode(ops, 1, lens)
+    b2, _, _ = _full_size_decode(ops, 2, lens)
+    assert torch.equal(a, b2), "output depends on the physical slot assignment"
+    c, _, _ = _full_size_decode(ops, 1, lens, scale_v=2.0)
+    assert torch.equal(c.float(), a.float() * 2.0)
+    v = v_log.float().view(256, 4096, 8, 128)
+    lo = v.amin(dim=1).repeat_interleave(2, dim=1)       # (seq, q head, dim) bounds from the kv head's values
+    hi = v.amax(dim=1).repeat_interleave(2, dim=1)
+    af = a.float()
+    assert ((af >= lo - 2 ** -6 * lo.abs() - 1e-3) & (af <= hi + 2 ** -6 * hi.abs() + 1e-3)).all()
+
+
+def test_decode_ragged_batch_with_empty_and_single_rows(ops):
+    """Ragged lengths including 0 and 1, and a one-row batch, against the oracle."""
+    _decode_case(ops, 41, [1], 16, 8)
+    _decode_case(ops, 42, [3, 1, 257, 1, 64, 1000, 2], 16, 8)
+    gen = torch.Generator().manual_seed(3)
+    kc, vc = _random_cache(gen, 64, 8)
+    ws = ops.DecodeWorkspace(3, 16, 8, DEV)
+    q = torch.randn(3, 16 * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    ops.decode_plan(torch.tensor([0, 0, 0], dtype=torch.int32, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV), ws)
+    out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 3, ws, 0.1)
+    assert not out.any(), "sequences with no keys must produce zeros"
+
+
+def test_prefill_full_size_causality(ops):
+    """The bench's 142 827 prompt tokens in one launch: changing the LAST key/value row of every sequence
+    may change only the last query's output (causality), bit for bit elsewhere."""
+    import bench
+
+    prompts, _ = bench.workload(256)
+    lens = [len(p) for p in prompts]
+    t_tok = sum(lens)
+    hq, hkv = 16, 8
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    kc = torch.randn(t_tok, hkv, 128, generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    vc = torch.randn(t_tok, hkv, 128, generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn(t_tok, hq * 128, generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    indptr_np = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    indptr = torch.from_numpy(indptr_np).to(DEV)
+    idx = torch.arange(t_tok, dtype=torch.int32, device=DEV)
+    plan = ops.prefill_plan_ws(len(lens), DEV)
+    ops.prefill_plan(indptr, plan)
+    base = ops.paged_prefill(q, kc, vc, indptr, indptr, idx, plan, hq, hkv, 128 ** -0.5)
+    last = torch.from_numpy(indptr_np[1:] - 1).long().to(DEV)
+    kc2, vc2 = kc.clone(), vc.clone()
+    kc2[last] = -kc2[last]
+    vc2[last] = vc2[last] * 3
+    changed = ops.paged_prefill(q, kc2, vc2, indptr, indptr, idx, plan, hq, hkv, 128 ** -0.5)
+    torch.cuda.synchronize()
+    keep = torch.ones(t_tok, dtype=torch.bool, device=DEV)
+    keep[last] = False
+    assert torch.equal(base[keep], changed[keep]), "a query saw a key that comes after it"
+    assert not torch.equal(base[last], changed[last])
+    assert torch.isfinite(base.float()).all()
+
+
+def test_sampler_edge_cases(ops):
+    gen = torch.Generator().manual_seed(77)
+    v = 151936
+    b = 256
+    logits = (torch.randn(b, v, generator=gen) * 2).to(torch.bfloat16).to(DEV)
+    ones = torch.ones(b, device=DEV)
+    full_k = torch.full((b,), v, dtype=torch.int64, device=DEV)
+    # top_k = 1 keeps the maximum and every token tied with it (sampler.py:72-75 masks `sorted < k-th value`),
+    # so the draw is a token whose logit equals the row maximum
+    top1 = ops.sample(logits, ones * 0.7, torch.ones(b, dtype=torch.int64, device=DEV), ones, ones * 0, 1, 2)
+    lf = logits.float()
+    assert (lf.gather(1, top1.view(-1, 1)).squeeze(1) == lf.max(-1).values).all()
+    # a tiny temperature concentrates the draw on the maximum (unfiltered, sliced path; 256 rows)
+    cold = ops.sample(logits, ones * 1e-3, full_k, ones, ones * 0, 3, 4)
+    assert (lf.gather(1, cold.view(-1, 1)).squeeze(1) == lf.max(-1).values).all()
+    # min_p = 1 keeps only the maximum; top_p -> 0 keeps only the maximum
+    only_max = ops.sample(logits[:8], ones[:8], full_k[:8], ones[:8], ones[:8], 5, 6)
+    assert (lf[:8].gather(1, only_max.view(-1, 1)).squeeze(1) == lf[:8].max(-1).values).all()
+    tiny_p = ops.sample(logits[:8], ones[:8], full_k[:8], ones[:8] * 1e-6, ones[:8] * 0, 7, 8)
+    assert (lf[:8].gather(1, tiny_p.view(-1, 1)).squeeze(1) == lf[:8].max(-1).values).all()
+    # a vocabulary that is not a multiple of 4 (Philox blocks serve 4 tokens) and all-equal logits: uniform draw
+    flat = torch.zeros(4000, 1001, dtype=torch.bfloat16, device=DEV)
+    n = flat.shape[0]
+    draws = ops.sample(flat, torch.ones(n, device=DEV), torch.full((n,), 1001, dtype=torch.int64, device=DEV),
+                       torch.ones(n, device=DEV), torch.zeros(n, device=DEV), 9, 10)
+    assert int(draws.min()) >= 0 and int(draws.max()) <= 1000
+    assert draws.unique().numel() > 900            # 4000 uniform draws over 1001 tokens hit almost all of them
+    # same seed and offset: same draws; another offset: other draws
+    again = ops.sample(flat, torch.ones(n, device=DEV), torch.full((n,), 1001, dtype=torch.int64, device=DEV),
+                       torch.ones(n, device=DEV), torch.zeros(n, device=DEV), 9, 10)
+    other = ops.sample(flat, torch.ones(n, device=DEV), torch.full((n,), 1001, dtype=torch.int64, device=DEV),
+                       torch.ones(n, device=DEV), torch.zeros(n, device=DEV), 9, 11)
+    assert torch.equal(draws, again) and not torch.equal(draws, other)
