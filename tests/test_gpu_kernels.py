@@ -654,3 +654,49 @@ def test_sampler_edge_cases(ops):
     other = ops.sample(flat, torch.ones(n, device=DEV), torch.full((n,), 1001, dtype=torch.int64, device=DEV),
                        torch.ones(n, device=DEV), torch.zeros(n, device=DEV), 9, 11)
     assert torch.equal(draws, again) and not torch.equal(draws, other)
+
+
+def test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops):
+    from oracle.attention_oracle import paged_attention_oracle
+
+    gen = torch.Generator().manual_seed(6)
+    hq, hkv, slots = 16, 8, 256
+    kc, vc = _random_cache(gen, slots, hkv)
+    kc = kc * 40            # q.k * scale reaches the hundreds: exp2 of the raw score would overflow
+    q = (torch.randn(2, hq, 128, generator=gen) * 4).to(torch.bfloat16)
+    valid = [torch.randperm(slots, generator=gen)[:70].to(torch.int32), torch.randperm(slots, generator=gen)[:9].to(torch.int32)]
+    # the listed slots of sequence 0 are interleaved with ids outside [0, slots): those are masked keys
+    listed0 = torch.stack([valid[0], torch.full((70,), -1, dtype=torch.int32)], 1).flatten()
+    listed0[5] = slots + 3
+    listed0[7] = 2 ** 31 - 1
+    kept0 = torch.tensor([s for s in listed0.tolist() if 0 <= s < slots], dtype=torch.int32)
+    flat = torch.cat([listed0, valid[1]]).to(DEV)
+    lens = [listed0.numel(), 9]
+    ws = ops.DecodeWorkspace(2, hq, hkv, DEV)
+    ops.decode_plan(torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor([0, lens[0]], dtype=torch.int64, device=DEV), ws)
+    out = ops.paged_decode(q.view(2, -1).to(DEV), kc.to(DEV), vc.to(DEV), flat, 2, ws, 128 ** -0.5).view(2, hq, 128)
+    ref_idx = torch.cat([kept0, valid[1]]).numpy()
+    ref = paged_attention_oracle(q.float(), kc, vc, np.arange(3), np.array([0, kept0.numel(), kept0.numel() + 9]), ref_idx, 128 ** -0.5)
+    assert torch.isfinite(out.float()).all()
+    attn_close(out, ref)
+
+
+def test_norm_and_rope_edge_rows(ops):
+    # all-zero rows normalise to zero (rsqrt(eps) is finite); huge rows do not overflow the fp32 sum of squares
+    w = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(3, 1024, dtype=torch.bfloat16, device=DEV)
+    x[1] = 3.0e4
+    x[2, 0] = float("nan")
+    y = ops.rmsnorm(x, w, 1e-6)
+    assert not y[0].any() and torch.allclose(y[1].float(), torch.ones(1024, device=DEV), atol=2 ** -7)
+    assert torch.isnan(y[2].float()).all()          # a NaN stays visible
+    # positions outside the cos/sin table are clamped, not read out of bounds
+    from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+    table = build_cos_sin_cache(128, 64, 1e6).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    q = torch.randn(3, 2 * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    k = torch.randn(3, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    pos = torch.tensor([63, 64, 10 ** 9], dtype=torch.int64, device=DEV)
+    q1, k1 = ops.rope(pos, q, k, table)
+    q2, k2 = ops.rope(torch.tensor([63, 63, 63], dtype=torch.int64, device=DEV), q, k, table)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2)
