@@ -38,7 +38,7 @@ extern "C" int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads
 }
 
 // plan_ws layout (int32): [0] n_items, [1] chunk, [2] batch, [3] max_items, [4..7] reserved,
-//   records[max_items][8], seq_first[batch], seq_nchunks[batch]
+//   records[max_items][8], seq_info[batch][2] = (first item, number of chunks) of every sequence
 __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __restrict__ kv_len,
                                                            const int64_t* __restrict__ kv_start,
                                                            const int64_t* __restrict__ out_slots, int batch, int hkv,
@@ -63,8 +63,7 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
     if (c < DEC_MIN_CHUNK) c = DEC_MIN_CHUNK;
     const int chunk = (int)(c > DEC_MAX_CHUNK ? DEC_MAX_CHUNK : c);   // small enough that len + chunk cannot overflow
     int32_t* recs = ws + 8;
-    int32_t* seq_first = recs + (int64_t)DEC_REC_INTS * max_items;
-    int32_t* seq_nch = seq_first + batch;
+    int32_t* seq_info = recs + (int64_t)DEC_REC_INTS * max_items;
     for (int base = 0; base < batch; base += 1024) {
         const int b = base + tid;
         int nch = 0, len = 0;
@@ -79,8 +78,8 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
         }
         const int first = carry + scan[tid] - nch;
         if (b < batch) {
-            seq_first[b] = first;
-            seq_nch[b] = nch;
+            seq_info[2 * b] = first;
+            seq_info[2 * b + 1] = nch;
             const int64_t start = kv_start[b];
             // slot the new token's K/V row goes to, recorded on the sequence's last chunk (QKV variant)
             long long new_slot = out_slots ? out_slots[b] : -1;
@@ -421,28 +420,30 @@ __global__ __launch_bounds__(256, (G <= 2 ? 4 : 2)) void paged_decode_kernel(
 
 // Combine the partials of sequences that were split over several chunks: one 128-thread block per
 // (sequence, query head), thread d owns output element d.  Blocks of unsplit sequences exit at once.
+// The kernel is a chain of dependent loads and nothing else, so the chain is kept at two hops: the
+// sequence's (first item, chunk count) pair in one load at an address known from the launch arguments,
+// then the chunks' partials, all independent, folded in one pass.
 __global__ __launch_bounds__(128) void decode_merge_kernel(const int32_t* __restrict__ plan, const float* __restrict__ partial,
-                                                           uint16_t* __restrict__ out, int hq_total) {
-    const int batch = plan[2], max_items = plan[3];
+                                                           uint16_t* __restrict__ out, int hq_total, int batch, int max_items) {
     const int b = blockIdx.x / hq_total, hq = blockIdx.x % hq_total;
     if (b >= batch) return;
-    const int32_t* seq_first = plan + 8 + (int64_t)DEC_REC_INTS * max_items;
-    const int nch = seq_first[batch + b];
+    const int2 info = *reinterpret_cast<const int2*>(plan + 8 + (int64_t)DEC_REC_INTS * max_items + 2 * b);
+    const int first = info.x, nch = info.y;
     if (nch <= 1) return;
-    const int first = seq_first[b];
     const int d = threadIdx.x;
     const float* base = partial + ((int64_t)first * hq_total + hq) * DEC_PART_STRIDE;
     const int64_t step = (int64_t)hq_total * DEC_PART_STRIDE;
-    float mall = -INFINITY;
-    for (int i = 0; i < nch; ++i) mall = fmaxf(mall, base[i * step + 128]);
-    const float mref = mall == -INFINITY ? 0.f : mall;
-    float lsum = 0.f, o = 0.f;
+    float mall = -INFINITY, lsum = 0.f, o = 0.f;
 #pragma unroll 4
     for (int i = 0; i < nch; ++i) {
         const float* p = base + i * step;
-        const float sc = __builtin_amdgcn_exp2f(p[128] - mref);
-        lsum += p[129] * sc;
-        o += p[d] * sc;
+        const float mi = p[128], li = p[129], ai = p[d];
+        const float mnew = fmaxf(mall, mi);
+        const float mref = mnew == -INFINITY ? 0.f : mnew;
+        const float so = __builtin_amdgcn_exp2f(mall - mref), sn = __builtin_amdgcn_exp2f(mi - mref);
+        lsum = lsum * so + li * sn;
+        o = o * so + ai * sn;
+        mall = mnew;
     }
     out[((int64_t)b * hq_total + hq) * 128 + d] = f32_to_bf16bits(lsum > 0.f ? o / lsum : 0.f);
 }
@@ -484,7 +485,7 @@ static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, 
     int rc = nvx_check_launch(who);
     if (rc) return rc;
     hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)(batch * n_q_heads)), dim3(128), 0, st, plan_ws, partial_ws,
-                       (uint16_t*)out, n_q_heads);
+                       (uint16_t*)out, n_q_heads, (int)batch, (int)dec_max_items(batch, n_kv_heads));
     return nvx_check_launch(who);
 }
 
