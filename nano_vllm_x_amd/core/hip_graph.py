@@ -43,7 +43,10 @@ class HIPGraph:
         """Record everything launched inside the block as the graph for batch size `bs`; graphs
         share one memory pool, so capture the largest first (cuda_graph.py:27-39)."""
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.graph_pool):
+        # with a process group alive its watchdog thread makes runtime calls of its own; "thread_local" keeps
+        # those from invalidating the capture going on in this thread
+        mode = "thread_local" if torch.distributed.is_available() and torch.distributed.is_initialized() else "global"
+        with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode=mode):
             yield
         if self.graph_pool is None:
             self.graph_pool = g.pool()
