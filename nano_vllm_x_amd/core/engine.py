@@ -16,10 +16,13 @@ from .scheduler import Scheduler
 
 
 class EngineCore:
-    def __init__(self, kv_cache_size: int, max_bs: int, context_len: int = 2048, prefix_reuse: bool = False):
+    def __init__(self, kv_cache_size: int, max_bs: int, context_len: int = 2048, prefix_reuse: bool = False,
+                 max_prefill_tokens: Optional[int] = None):
         self.context_len = context_len
         self.prefix_reuse = prefix_reuse
-        self.scheduler = Scheduler(kv_cache_size=kv_cache_size, max_bs=max_bs, prefix_reuse=prefix_reuse)
+        self.max_prefill_tokens = max_prefill_tokens
+        self.scheduler = Scheduler(kv_cache_size=kv_cache_size, max_bs=max_bs, prefix_reuse=prefix_reuse,
+                                   max_prefill_tokens=max_prefill_tokens)
 
     def add_sequence(self, sequence_id: str, prompt_token_ids: list, sampling_params: SamplingParams):
         if len(prompt_token_ids) > self.context_len:   # keep the tail (engine.py:59-60)
@@ -67,7 +70,8 @@ class Engine(EngineCore):
 
     def __init__(self, model: str, gpu_memory_utilization: float, max_bs: int, tp_size: int = 1, pp_size: int = 1,
                  nccl_port: int = 29500, device_ids: Optional[list] = None, enforce_eager: bool = False,
-                 context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0, prefix_reuse: bool = False):
+                 context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0, prefix_reuse: bool = False,
+                 max_prefill_tokens: Optional[int] = None):
         from .model_runner import ModelRunner
 
         if pp_size != 1:
@@ -80,7 +84,8 @@ class Engine(EngineCore):
             kv_cache_size = self.model_runner.profile_kv_cache_size(gpu_memory_utilization)
         self.kv_cache_size = kv_cache_size
         self.model_runner.initialize_kv_cache(kv_cache_size)
-        super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len, prefix_reuse=prefix_reuse)
+        super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len, prefix_reuse=prefix_reuse,
+                         max_prefill_tokens=max_prefill_tokens)
         self.scheduler.on_release = self.model_runner.release_sequence
         self._inflight = None
 
@@ -118,7 +123,8 @@ class Engine(EngineCore):
             self._inflight = None
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
-        self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse)
+        self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse,
+                                   max_prefill_tokens=self.max_prefill_tokens)
         self.scheduler.on_release = self.model_runner.release_sequence
 
     def wait_until_ready(self):

@@ -32,10 +32,16 @@ from .kv_cache import KVCacheManager
 
 
 class Scheduler:
-    def __init__(self, kv_cache_size: int, max_bs: int = 32, prefix_reuse: bool = False):
+    def __init__(self, kv_cache_size: int, max_bs: int = 32, prefix_reuse: bool = False,
+                 max_prefill_tokens: Optional[int] = None):
         self.kv_cache_size = kv_cache_size
         self.max_bs = max_bs
         self.prefix_reuse = prefix_reuse
+        # Optional cap on the tokens one prefill step computes (the reference has none: a burst of long
+        # prompts becomes one arbitrarily large batch, scheduler.py:67-80).  None keeps the reference's
+        # behaviour; with a cap, admission stops before the step would exceed it (one sequence is always
+        # admitted, however long).
+        self.max_prefill_tokens = max_prefill_tokens
         self.sequences: dict = {}
         self.waiting: Deque[Sequence] = deque()
         self.running: Deque[Sequence] = deque()
@@ -87,7 +93,12 @@ class Scheduler:
         escape and the engine dies); it is re-raised only if nothing is running that could ever
         release memory."""
         picked = []
+        budget = self.max_prefill_tokens
         while self.waiting and len(picked) < self.max_bs:
+            if budget is not None and picked:
+                head = self.waiting[0]
+                if sum(len(s.token_ids) - s.cached_kv_len for s in picked) + len(head.token_ids) > budget:
+                    break
             seq = self.waiting.popleft()
             try:
                 if self.prefix_reuse and not seq.kv_indices:

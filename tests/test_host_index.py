@@ -80,3 +80,29 @@ def test_single_sequence_too_large_returns_none():
     e.update_from_output(b, [9])
     assert e.scheduler.schedule() is None     # no slot, nobody to preempt: the step yields nothing
     assert [s.seq_id for s in e.scheduler.running] == ["a"]
+
+
+def test_prefill_token_budget_is_opt_in_and_never_starves():
+    """Scheduler(max_prefill_tokens=...) caps the tokens of one prefill step; None (default) is the
+    reference's unbounded admission (scheduler.py:67-80)."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    lens = [30, 50, 10, 200, 5, 5]
+
+    def prefill_batches(budget):
+        core = EngineCore(kv_cache_size=2000, max_bs=8, max_prefill_tokens=budget)
+        for i, n in enumerate(lens):
+            core.add_sequence(f"s{i}", list(range(n)), SamplingParams(ignore_eos=True, max_new_tokens=2))
+        out = []
+        while core.has_unfinished_sequences():
+            b = core.scheduler.schedule()
+            if b.forward_mode == ForwardMode.PREFILL:
+                out.append([len(s.token_ids) for s in b.seqs])
+            core.update_from_output(b, [1] * b.num_seqs)
+        return out
+
+    assert prefill_batches(None) == [lens]
+    capped = prefill_batches(100)
+    assert capped == [[30, 50, 10], [200], [5, 5]]          # FCFS order kept; the 200-token prompt runs alone
+    assert all(sum(b) <= 100 or len(b) == 1 for b in capped)
