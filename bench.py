@@ -253,8 +253,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": round(nominal / wall / A100_PUBLISHED, 3),
         "dtype": "bf16", "data": "synthetic (random token ids, seed 0; random-init weights of the Qwen3-0.6B architecture)",
         "config": {"workload": f"reference bench.py: {args.num_seqs} requests, prompt U[100,1024], max_tokens U[100,1024], "
-                               "temperature 0.6, ignore_eos, all submitted at once",
-                   "model": args.model, "parallelism": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
+                               f"temperature 0.6, ignore_eos, all submitted at once, {args.model} geometry",
+                   "geometry": args.model, "ranks": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
                    "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph"},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
         "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
