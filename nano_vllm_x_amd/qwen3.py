@@ -82,6 +82,10 @@ def load_config(model: str) -> Qwen3Config:
 # GEMM, per projection; measured on MI355X with the Qwen3-0.6B shapes (tools/kernel_bench.py linear).
 # Above these, and for every prefill, the projection is a library GEMM.
 DECODE_LINEAR_MAX_ROWS = {"qkv": 176, "o": 256, "gate_up": 256, "down": 256}
+# ... and largest weight matrix.  The skinny kernel wins where a projection is latency-bound (a few MB of
+# weights: one slice per workgroup, fetched in one go); a matrix of tens of MB is a bandwidth-bound stream,
+# which the library GEMM sustains better (Qwen3-8B o_proj, 33 MB: 28 us here vs ~12 us of streaming).
+DECODE_LINEAR_MAX_WEIGHT_BYTES = 16 << 20
 
 
 def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
@@ -90,7 +94,8 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Ten
     follows sums; "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
     rows, k = x.shape
     n = weight.shape[0]
-    use = x.is_cuda and x.dtype == torch.bfloat16 and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
+    use = (x.is_cuda and x.dtype == torch.bfloat16 and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
+           and n * k * 2 <= DECODE_LINEAR_MAX_WEIGHT_BYTES)
     if kind in ("o", "down"):
         splits = ops.linear_decode_splits(n, k) if use and tpd.tp_size() == 1 and n % 16 == 0 else 0
         if splits:
