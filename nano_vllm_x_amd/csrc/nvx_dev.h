@@ -37,8 +37,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16bits(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
+// two conversions in one v_cvt_pk_bf16_f32 (round to nearest even, as the scalar conversion)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16bits(lo) | ((uint32_t)f32_to_bf16bits(hi) << 16);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // value of f after a round trip through bf16 (what eager bf16 arithmetic keeps of every result)
 __device__ __forceinline__ float round_bf16(float f) { return bf16bits_to_f32(f32_to_bf16bits(f)); }

@@ -68,51 +68,89 @@ extern "C" int nvx_prefill_plan(const int32_t* qo_indptr, int64_t batch, int32_t
     return nvx_check_launch("nvx_prefill_plan");
 }
 
-// Staging registers of one 64-key tile (K and V rows of 256 B, 16 lanes per row).  Named members, not
-// arrays: arrays that live across the tile loop were left in scratch memory by the compiler.
-struct PfStage { nvx_u32x4 k0, k1, k2, k3, v0, v1, v2, v3; };
+// Slot ids of the rows this thread moves for one tile.  They are fetched a tile before the rows, so the
+// row loads never wait for them (block table -> row is a dependent chain otherwise paid on every tile).
+struct PfSlots { int s0, s1, s2, s3; };
 
-template <int KEYS_PER_PASS>
-__device__ __forceinline__ void pf_gather_one(nvx_u32x4& kd, nvx_u32x4& vd, int p, int tile, int krow0, int lkv,
-                                              const int32_t* __restrict__ seq_slots, int64_t n_slots,
-                                              const uint16_t* __restrict__ kbase, const uint16_t* __restrict__ vbase,
-                                              int64_t row_elems) {
-    int key = tile * PF_KVBLK + krow0 + p * KEYS_PER_PASS;
-    key = key < lkv ? key : lkv - 1;   // rows past the end are masked later
-    int64_t slot = seq_slots[key];
-    slot = (slot < 0 || slot >= n_slots) ? 0 : slot;
-    kd = *reinterpret_cast<const nvx_u32x4*>(kbase + slot * row_elems);
-    vd = *reinterpret_cast<const nvx_u32x4*>(vbase + slot * row_elems);
+// The loads are issued from inline assembly, like the row copies below, so that the compiler's own wait
+// counting never has to drain the row copies in order to hand over a slot id; pf_wait<N>() makes them
+// usable (it takes the registers as operands, so no use can be scheduled ahead of it).
+__device__ __forceinline__ int pf_load_i32(const int32_t* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
 }
 template <int PASSES, int KEYS_PER_PASS>
-__device__ __forceinline__ void pf_gather(PfStage& st, int tile, int krow0, int lkv, const int32_t* __restrict__ seq_slots,
-                                          int64_t n_slots, const uint16_t* __restrict__ kbase,
-                                          const uint16_t* __restrict__ vbase, int64_t row_elems) {
-    pf_gather_one<KEYS_PER_PASS>(st.k0, st.v0, 0, tile, krow0, lkv, seq_slots, n_slots, kbase, vbase, row_elems);
-    pf_gather_one<KEYS_PER_PASS>(st.k1, st.v1, 1, tile, krow0, lkv, seq_slots, n_slots, kbase, vbase, row_elems);
+__device__ __forceinline__ void pf_load_slots(PfSlots& sl, int tile, int krow0, int lkv, const int32_t* __restrict__ seq_slots) {
+    const int last = lkv - 1;   // rows past the end are masked later
+    const int key = tile * PF_KVBLK + krow0;
+    sl.s0 = pf_load_i32(seq_slots + min(key, last));
+    sl.s1 = pf_load_i32(seq_slots + min(key + KEYS_PER_PASS, last));
     if constexpr (PASSES == 4) {
-        pf_gather_one<KEYS_PER_PASS>(st.k2, st.v2, 2, tile, krow0, lkv, seq_slots, n_slots, kbase, vbase, row_elems);
-        pf_gather_one<KEYS_PER_PASS>(st.k3, st.v3, 3, tile, krow0, lkv, seq_slots, n_slots, kbase, vbase, row_elems);
+        sl.s2 = pf_load_i32(seq_slots + min(key + 2 * KEYS_PER_PASS, last));
+        sl.s3 = pf_load_i32(seq_slots + min(key + 3 * KEYS_PER_PASS, last));
+    } else {
+        sl.s2 = sl.s3 = 0;
     }
 }
-__device__ __forceinline__ void pf_write_one(const nvx_u32x4& kd, const nvx_u32x4& vd, int key, int piece, unsigned char* k_lds,
-                                             unsigned char* v_lds) {
-    *reinterpret_cast<nvx_u32x4*>(k_lds + key * 256 + ((piece ^ (key & 15)) << 4)) = kd;
-    *reinterpret_cast<nvx_u32x4*>(v_lds + key * 256 + ((piece ^ ((key & 3) << 2)) << 4)) = vd;
+// Wait until at most N of this wave's vector-memory operations are still in flight (they complete in
+// issue order), and tie the slot registers to the wait.
+template <int N>
+__device__ __forceinline__ void pf_wait(PfSlots& sl) {
+    static_assert(N == 0 || N == 4 || N == 8, "vmcnt immediates used here");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
 }
+// One row pair (K and V, 256 B each, 16 lanes per row) straight from the pool into LDS, no register
+// staging: a wave instruction writes 64 consecutive 16-byte slots (4 rows) starting at a wave-uniform
+// LDS address, so the swizzle is applied on the global side: the lane that fills position `pos` of row r
+// fetches piece pos ^ swz(r).
+// The copy is issued from inline assembly: through the compiler's builtin every later LDS read is held
+// back until the copy has landed (the compiler cannot tell the two buffers apart), which puts the whole
+// HBM latency in front of every tile.  The waits are therefore explicit: pf_wait<N>() before the barrier
+// that publishes a tile.
+__device__ __forceinline__ void pf_dma16(const unsigned char* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");   // m0 has no other user in this kernel
+}
+// LDS reads by 32-bit LDS address (address arithmetic with XOR would hide the address space from the
+// compiler if it were done on generic pointers)
+typedef __attribute__((address_space(3))) const nvx_u32x4 pf_lds_u4;
+__device__ __forceinline__ nvx_u32x4 pf_lds_read16(unsigned addr) { return *reinterpret_cast<pf_lds_u4*>((uintptr_t)addr); }
+__device__ __forceinline__ pf_s16x4 pf_lds_read_tr(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<pf_lds_s16x4*>((uintptr_t)addr));
+}
+__device__ __forceinline__ unsigned pf_lds_addr(const unsigned char* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+// kbase / vbase already include the head and this lane's (swizzled) piece; unsigned 32-bit slot
+// arithmetic keeps an address at one compare, one select and one 64-bit multiply-add
+__device__ __forceinline__ void pf_gather_one(int slot_id, unsigned n_slots, const unsigned char* __restrict__ kbase,
+                                              const unsigned char* __restrict__ vbase, unsigned row_bytes,
+                                              unsigned k_dst, unsigned v_dst) {
+    unsigned slot = (unsigned)slot_id;   // -1 -> 0xffffffff: out of range
+    slot = slot < n_slots ? slot : 0u;
+    const unsigned long long off = (unsigned long long)slot * row_bytes;
+    pf_dma16(kbase + off, k_dst);
+    pf_dma16(vbase + off, v_dst);
+}
+// k_dst / v_dst: start of this WAVE's four rows of pass 0 in the tile buffer (wave-uniform)
 template <int PASSES, int KEYS_PER_PASS>
-__device__ __forceinline__ void pf_stage_write(const PfStage& st, unsigned char* k_lds, unsigned char* v_lds, int krow0, int piece) {
-    pf_write_one(st.k0, st.v0, krow0, piece, k_lds, v_lds);
-    pf_write_one(st.k1, st.v1, krow0 + KEYS_PER_PASS, piece, k_lds, v_lds);
+__device__ __forceinline__ void pf_gather(const PfSlots& sl, unsigned n_slots, const unsigned char* __restrict__ kbase,
+                                          const unsigned char* __restrict__ vbase, unsigned row_bytes,
+                                          unsigned k_dst, unsigned v_dst) {
+    constexpr int STEP = KEYS_PER_PASS * 256;
+    pf_gather_one(sl.s0, n_slots, kbase, vbase, row_bytes, k_dst, v_dst);
+    pf_gather_one(sl.s1, n_slots, kbase, vbase, row_bytes, k_dst + STEP, v_dst + STEP);
     if constexpr (PASSES == 4) {
-        pf_write_one(st.k2, st.v2, krow0 + 2 * KEYS_PER_PASS, piece, k_lds, v_lds);
-        pf_write_one(st.k3, st.v3, krow0 + 3 * KEYS_PER_PASS, piece, k_lds, v_lds);
+        pf_gather_one(sl.s2, n_slots, kbase, vbase, row_bytes, k_dst + 2 * STEP, v_dst + 2 * STEP);
+        pf_gather_one(sl.s3, n_slots, kbase, vbase, row_bytes, k_dst + 3 * STEP, v_dst + 3 * STEP);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
+template <int G, int NWAVES, int NBUF>
+__global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ qo_indptr,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, const int32_t* __restrict__ plan,
@@ -123,9 +161,12 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
     constexpr int TAB = QPOS == 32 ? 0 : (QPOS == 64 ? 1 : 2);
     constexpr int KEYS_PER_PASS = NT / 16;    // 16 lanes move one 256-byte row
     constexpr int PASSES = PF_KVBLK / KEYS_PER_PASS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* k_lds = smem;                      // [64 keys][256 B], pieces swizzled by key & 15
-    unsigned char* v_lds = smem + PF_KVBLK * 256;     // [64 keys][256 B], pieces swizzled by (key & 3) << 2
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    // NBUF tile buffers of [K: 64 keys x 256 B, pieces swizzled by key & 15][V: same, swizzled by (key & 3) << 2]
+    constexpr int BUF_BYTES = 2 * PF_KVBLK * 256;
+    constexpr int DIST = NBUF - 1;            // tiles the row copies run ahead of the computation
+    constexpr int PER_TILE = 2 * PASSES;      // row-copy instructions per wave and tile
+    static_assert(NBUF == 2 || NBUF == 3, "ring of two or three tile buffers");
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l32 = lane & 31;
@@ -134,13 +175,23 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
     const int unit = blockIdx.x;
     const int gblk = unit / hkv, head = unit % hkv;
     if (gblk >= total_blocks) return;
-    // sequence that owns query block gblk: last b with tab[1 + b] <= gblk
-    int lo = 0, hi = batch - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tab[1 + mid] <= gblk) lo = mid; else hi = mid - 1;
-    }
-    const int b = lo;
+    // Sequence that owns query block gblk: the last b with tab[1 + b] <= gblk.  The table is
+    // non-decreasing, so b + 1 is the number of entries <= gblk: every thread tests some entries and the
+    // workgroup adds up.  (A binary search is log2(batch) dependent loads, several microseconds in front
+    // of every workgroup's first tile; this is one.)
+    // (the counters sit behind the tile buffers: the fragment addressing XORs address bits and needs the
+    // buffers at a 256-byte boundary, which a static LDS array in front of them would break)
+    int* owner_count = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
+    int below = 0;
+    for (int i = tid; i < batch; i += NT) below += tab[1 + i] <= gblk ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) below += __shfl_xor(below, m, 64);
+    if (lane == 0) owner_count[wave] = below;
+    __syncthreads();
+    int b = -1;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) b += owner_count[w];
+    b = __builtin_amdgcn_readfirstlane(b < 0 ? 0 : b);
     const int qb = gblk - tab[1 + b];
     const int q0 = qo_indptr[b], lq = qo_indptr[b + 1] - q0;
     const int kv0 = kv_indptr[b], lkv = kv_indptr[b + 1] - kv0;
@@ -155,7 +206,6 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
     const int wave_last_key = qb * QPOS + pb * 32 + 31 + offset;  // last key any query of this wave sees
     const int wave_first_vis = qb * QPOS + pb * 32 + offset;      // last key the wave's FIRST query sees
     const int n_tiles = (kmax + PF_KVBLK - 1) / PF_KVBLK;
-    const int64_t row_elems = (int64_t)hkv * 128;
 
     // Q^T fragments: 8 k-steps of 16 dims; lane holds dims 16*ks + 8*half .. +7 of its query row
     nvx_bf16x8 qf[8];
@@ -176,40 +226,94 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging registers for the tile after the one being computed
-    PfStage stage;
-    static_assert(PASSES == 2 || PASSES == 4, "tile staging is written for 256- or 512-thread workgroups");
-    const int piece = tid & 15, krow0 = tid >> 4;
-    const int gofs = head * 128 + piece * 8;
-    if (n_tiles > 0) pf_gather<PASSES, KEYS_PER_PASS>(stage, 0, krow0, lkv, kv_indices + kv0, n_slots, k_cache + gofs, v_cache + gofs, row_elems);
+    static_assert(PASSES == 2 || PASSES == 4, "tile gather is written for 256- or 512-thread workgroups");
+    // Pipeline, one barrier per tile, ring of NBUF tile buffers: while tile t is computed, the rows of tiles
+    // t + 1 .. t + DIST travel from the pool into the other buffers and the slot ids of tile t + DIST + 1
+    // into registers.  At the end of tile t the wave waits only until tile t + 1 has landed (operations
+    // complete in issue order, so "all but the youngest PER_TILE" when a further tile is in flight).
+    const int pos = tid & 15, krow0 = tid >> 4;
+    const int32_t* seq_slots = kv_indices + kv0;
+    // this lane's piece of a row: KEYS_PER_PASS is a multiple of 16, so the swizzle is the same for every pass
+    const unsigned char* kg = reinterpret_cast<const unsigned char*>(k_cache) + head * 256 + ((pos ^ (krow0 & 15)) << 4);
+    const unsigned char* vg = reinterpret_cast<const unsigned char*>(v_cache) + head * 256 + ((pos ^ ((krow0 & 3) << 2)) << 4);
+    const unsigned row_bytes = (unsigned)hkv * 256u;
+    const unsigned n_slots_u = n_slots > 0xffffffffll ? 0xffffffffu : (unsigned)n_slots;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave * 4 * 256);
+    const unsigned lds0 = pf_lds_addr(smem);
+    // per-lane byte offsets of the fragment reads inside a tile buffer (see the reads below)
+    const int k_lane_off = l32 * 256 + ((half ^ (l32 & 15)) << 4);
+    const int v_lane_off = [&] {
+        const int grp = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+        const int row = 4 * half + tq;
+        const int pc0 = 2 * (grp & 1) + (tp >> 1);
+        return row * 256 + ((pc0 ^ ((row & 3) << 2)) << 4) + 8 * (tp & 1);
+    }();
+    PfSlots slots, slots_next;
+    unsigned ring0 = lds0, ring1 = lds0 + BUF_BYTES, ring2 = lds0 + (NBUF - 1) * BUF_BYTES;   // this tile, next, the one after
+    if (n_tiles > 0) {
+        pf_load_slots<PASSES, KEYS_PER_PASS>(slots, 0, krow0, lkv, seq_slots);
+        pf_load_slots<PASSES, KEYS_PER_PASS>(slots_next, 1, krow0, lkv, seq_slots);
+        pf_wait<0>(slots);
+        pf_wait<0>(slots_next);
+        pf_gather<PASSES, KEYS_PER_PASS>(slots, n_slots_u, kg, vg, row_bytes, ring0 + wave_rows, ring0 + PF_KVBLK * 256 + wave_rows);
+        if constexpr (DIST == 2) {
+            if (n_tiles > 1) {
+                pf_load_slots<PASSES, KEYS_PER_PASS>(slots, 2, krow0, lkv, seq_slots);   // older than the copies of tile 1
+                pf_gather<PASSES, KEYS_PER_PASS>(slots_next, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
+                pf_wait<PER_TILE>(slots);    // tile 0 and the slot ids of tile 2 are in; tile 1 may still fly
+            } else {
+                pf_wait<0>(slots);
+            }
+        } else {
+            slots = slots_next;
+            pf_wait<0>(slots);
+        }
+    }
+    __syncthreads();
+    // invariant at the top of tile t: `slots` holds the ids of tile t + DIST
     for (int tile = 0; tile < n_tiles; ++tile) {
-        __syncthreads();            // every wave is done reading the previous tile
-        pf_stage_write<PASSES, KEYS_PER_PASS>(stage, k_lds, v_lds, krow0, piece);
-        __syncthreads();            // tile visible
-        if (tile + 1 < n_tiles) pf_gather<PASSES, KEYS_PER_PASS>(stage, tile + 1, krow0, lkv, kv_indices + kv0, n_slots, k_cache + gofs, v_cache + gofs, row_elems);
+        const unsigned k_lds = ring0;   // LDS byte addresses
+        const unsigned v_lds = k_lds + PF_KVBLK * 256;
+        const bool more = tile + DIST < n_tiles;
+        if (more) {   // its buffer held tile t - 1 (or t + 1 - NBUF): every wave left it before the last barrier
+            const unsigned kn = (DIST == 2 ? ring2 : ring1) + wave_rows;
+            pf_load_slots<PASSES, KEYS_PER_PASS>(slots_next, tile + DIST + 1, krow0, lkv, seq_slots);
+            pf_gather<PASSES, KEYS_PER_PASS>(slots, n_slots_u, kg, vg, row_bytes, kn, kn + PF_KVBLK * 256);
+        }
 
         const int key_base = tile * PF_KVBLK;
-        if (key_base > wave_last_key) continue;   // wave-uniform: nothing in this tile is visible to this wave
+        if (key_base <= wave_last_key) {   // wave-uniform: otherwise nothing in this tile is visible to this wave
 
         // ---- S^T = K . Q^T ----
+        // all sixteen K fragments are requested before the first MFMA, and the two 32-key blocks
+        // alternate so that no MFMA waits for the one before it
         nvx_f32x16 st[2];
+        nvx_u32x4 kf[2][8];
+        // fragment ks of key row l32 (+32 for the second block) sits at piece (2 ks + half) ^ (key & 15): one
+        // per-tile base, the k-step applied as an XOR on the address bits, the block as an immediate offset
+        const unsigned kfrag0 = k_lds + k_lane_off;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-            const int key = kb * 32 + l32;
-            const unsigned char* krow = k_lds + key * 256;
+            for (int ks = 0; ks < 8; ++ks)
+                kf[kb][ks] = pf_lds_read16((kfrag0 ^ (ks << 5)) + kb * 32 * 256);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const uint4 a = *reinterpret_cast<const uint4*>(krow + (((2 * ks + half) ^ (key & 15)) << 4));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, a), qf[ks], st[kb], 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
         }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, kf[kb][ks]), qf[ks], st[kb], 0, 0, 0);
+        // scheduling order for this region: the sixteen LDS reads, then the sixteen MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         // ---- mask, online softmax (this lane: one query, 32 of the tile's 64 keys) ----
         // Scores stay unscaled; the scale rides on the fused multiply-add inside the exponent.  Only
         // tiles that cross the causal diagonal (or the end of the sequence) pay for the mask.
         const int vis = q_ok ? qi + offset : -1;   // last visible key index of this lane's query
         if (key_base + PF_KVBLK - 1 > wave_first_vis) {   // wave-uniform
+            asm volatile("" : : : "memory");   // keeps the branch: as selects on every tile the mask costs 96 VALU ops
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -235,43 +339,65 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_prefill_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
         }
-        nvx_bf16x8 pf[2][2];
+        // ---- P^T, then O^T += V^T . P^T ----
+        // V^T fragment element j of lane half h is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the 32-key block; the
+        // transpose read hands lane i of a 16-lane group column i of a 4-key x 16-dim block.  The lane
+        // addresses row 4 half + tq (+ 16 s2 + 32 kb, and + 8 for the second read: immediate offsets); the
+        // dim block d enters the swizzled piece index as an XOR on address bits 6-7.
+        // Order, fixed with scheduling barriers because the compiler otherwise sinks every LDS read to
+        // just before its MFMA and waits out the LDS latency 32 times per tile: the V fragments of the
+        // first two (kb, s2) groups are requested before the exponentials and land under them; each group
+        // of four MFMAs is followed by the reads of the group two ahead.
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const unsigned vfrag0 = v_lds + v_lane_off;
+        s16x8 vf[4][4];
+        auto read_group = [&](int grp_i) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                uint32_t w[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j], scale_log2, -mref));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j + 1], scale_log2, -mref));
-                    l_run += p0 + p1;
-                    w[j] = pack_bf16x2(p0, p1);
-                }
-                pf[kb][s2] = __builtin_bit_cast(nvx_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            for (int d = 0; d < 4; ++d) {
+                const unsigned pa = (vfrag0 ^ (d << 6)) + grp_i * 16 * 256;   // group = 2 kb + s2: 16 keys each
+                const pf_s16x4 va = pf_lds_read_tr(pa);
+                const pf_s16x4 vb = pf_lds_read_tr(pa + 8 * 256);
+                vf[grp_i][d] = s16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
             }
-        // ---- O^T += V^T . P^T ----
-        // fragment element j of lane half h is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the 32-key block;
-        // the transpose read hands lane i of a 16-lane group column i of a 4-key x 16-dim block
-        const int grp = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+        };
+        read_group(0);
+        read_group(1);
+        __builtin_amdgcn_sched_barrier(0);
+        nvx_bf16x8 pf[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int gi = 0; gi < 4; ++gi) {
+            const int kb = gi >> 1, s2 = gi & 1;
+            uint32_t w[4];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int key_a = kb * 32 + 16 * s2 + 4 * half + tq;   // row this lane addresses, first read
-                const int key_b = key_a + 8;                            // second read
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int pc = d * 4 + 2 * (grp & 1) + (tp >> 1);
-                    const unsigned char* pa = v_lds + key_a * 256 + ((pc ^ ((key_a & 3) << 2)) << 4) + 8 * (tp & 1);
-                    const unsigned char* pbp = v_lds + key_b * 256 + ((pc ^ ((key_b & 3) << 2)) << 4) + 8 * (tp & 1);
-                    const pf_s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pf_lds_s16x4*)pa);
-                    const pf_s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pf_lds_s16x4*)pbp);
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, vf), pf[kb][s2], o_acc[d], 0, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j], scale_log2, -mref));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j + 1], scale_log2, -mref));
+                l_run += p0 + p1;
+                w[j] = pack_bf16x2(p0, p1);
             }
+            pf[gi] = __builtin_bit_cast(nvx_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, vf[gi][d]), pf[gi], o_acc[d], 0, 0, 0);
+            if (gi + 2 < 4) read_group(gi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        if (more) {
+            if constexpr (DIST == 2) pf_wait<PER_TILE>(slots_next); else pf_wait<0>(slots_next);
+            slots = slots_next;
+        } else {
+            pf_wait<0>(slots);
+        }
+        __syncthreads();   // tile + 1 visible; this tile's buffer free
+        {
+            const unsigned t0 = ring0;
+            if constexpr (NBUF == 3) { ring0 = ring1; ring1 = ring2; ring2 = t0; } else { ring0 = ring1; ring1 = t0; ring2 = t0; }
+        }
     }
 
     // ---- epilogue: O = O^T / l, one query per lane, dims in registers ----
@@ -306,20 +432,26 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
     const int g = n_q_heads / n_kv_heads;
     const float scale_log2 = sm_scale * PF_LOG2E;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 2 * PF_KVBLK * 256;
-#define NVX_PF(GG, NW, QPOS)                                                                                          \
-    do {                                                                                                               \
-        const int64_t blocks = ((n_tokens + (QPOS) - 1) / (QPOS) + batch) * n_kv_heads;                                \
-        hipLaunchKernelGGL((paged_prefill_kernel<GG, NW>), dim3((unsigned)blocks), dim3((NW) * 64), lds, st,           \
-                           (const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache,       \
-                           n_slots, qo_indptr, kv_indptr, kv_indices, plan_ws, (uint16_t*)out, (int)batch, n_kv_heads, \
-                           scale_log2);                                                                                \
+    const size_t buf_bytes = 2 * PF_KVBLK * 256, tail_bytes = 64;   // tile buffers + per-wave counters
+#define NVX_PF(GG, NW, QPOS, NB)                                                                                       \
+    do {                                                                                                                \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)paged_prefill_kernel<GG, NW, NB>,               \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((NB) * buf_bytes + tail_bytes)); \
+        NVX_REQUIRE(attr == hipSuccess, NVX_ELAUNCH, "nvx_paged_prefill: cannot reserve %d KB of LDS", (int)((NB) * buf_bytes / 1024)); \
+        const int64_t blocks = ((n_tokens + (QPOS) - 1) / (QPOS) + batch) * n_kv_heads;                                 \
+        hipLaunchKernelGGL((paged_prefill_kernel<GG, NW, NB>), dim3((unsigned)blocks), dim3((NW) * 64), (NB) * buf_bytes + tail_bytes, st, \
+                           (const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache,        \
+                           n_slots, qo_indptr, kv_indptr, kv_indices, plan_ws, (uint16_t*)out, (int)batch, n_kv_heads,  \
+                           scale_log2);                                                                                 \
     } while (0)
     switch (g) {
-        case 1: NVX_PF(1, 4, 128); break;
-        case 2: NVX_PF(2, 8, 128); break;
-        case 4: NVX_PF(4, 4, 32); break;
-        case 8: NVX_PF(8, 8, 32); break;
+        case 1: NVX_PF(1, 4, 128, 2); break;
+        // two 4-wave workgroups per CU (each in its own phase of the tile loop) measured faster than one
+        // 8-wave workgroup of 128 queries (0.75 vs 0.86 ms on the bench prompts); a third tile buffer (row
+        // copies two tiles ahead) changed neither
+        case 2: NVX_PF(2, 4, 64, 2); break;
+        case 4: NVX_PF(4, 4, 32, 2); break;
+        case 8: NVX_PF(8, 8, 32, 2); break;
         default: return nvx_fail(NVX_EUNSUPPORTED, "nvx_paged_prefill: query/kv head ratio %d not in {1,2,4,8}", g);
     }
 #undef NVX_PF

@@ -124,6 +124,8 @@ def cmd_decode(args):
 def cmd_prefill(args):
     prompts, _ = bench.workload(args.num_seqs)
     lens = [len(p) for p in prompts]
+    if args.uniform_len:   # every sequence the same length: separates steady-state rate from per-workgroup overheads
+        lens = [args.uniform_len] * max(1, 131072 // args.uniform_len)
     t_tok = sum(lens)
     slots = t_tok + 1024
     kc = torch.randn(4, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
@@ -211,5 +213,6 @@ if __name__ == "__main__":
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--hkv1", action="store_true")
     ap.add_argument("--qkv", action="store_true")
+    ap.add_argument("--uniform-len", type=int, default=0)
     a = ap.parse_args()
     {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "linear": cmd_linear}[a.cmd](a)
