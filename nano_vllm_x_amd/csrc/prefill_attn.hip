@@ -68,50 +68,36 @@ extern "C" int nvx_prefill_plan(const int32_t* qo_indptr, int64_t batch, int32_t
     return nvx_check_launch("nvx_prefill_plan");
 }
 
-// Slot ids of the rows this thread moves for one tile.  They are fetched a tile before the rows, so the
-// row loads never wait for them (block table -> row is a dependent chain otherwise paid on every tile).
-struct PfSlots { int s0, s1, s2, s3; };
-
-// The loads are issued from inline assembly, like the row copies below, so that the compiler's own wait
-// counting never has to drain the row copies in order to hand over a slot id; pf_wait<N>() makes them
-// usable (it takes the registers as operands, so no use can be scheduled ahead of it).
-__device__ __forceinline__ int pf_load_i32(const int32_t* p) {
-    int v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
+// Slot ids of a tile (64 keys) travel block table -> LDS one tile before the rows they name, as ONE
+// 256-byte copy issued by wave 0 (lane l fetches the id of key l).  No thread holds ids that are still
+// in flight: a load issued from inline assembly hands the compiler a register whose value arrives
+// later, and nothing stops the register allocator from copying that register before then (seen as rare
+// wrong rows); a load the compiler knows of makes it wait for the row copies as well.
+__device__ __forceinline__ void pf_dma4(const int32_t* g, unsigned lds_addr) {
+    const unsigned uni = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(uni) : "memory");
 }
-template <int PASSES, int KEYS_PER_PASS>
-__device__ __forceinline__ void pf_load_slots(PfSlots& sl, int tile, int krow0, int lkv, const int32_t* __restrict__ seq_slots) {
-    const int last = lkv - 1;   // rows past the end are masked later
-    const int key = tile * PF_KVBLK + krow0;
-    sl.s0 = pf_load_i32(seq_slots + min(key, last));
-    sl.s1 = pf_load_i32(seq_slots + min(key + KEYS_PER_PASS, last));
-    if constexpr (PASSES == 4) {
-        sl.s2 = pf_load_i32(seq_slots + min(key + 2 * KEYS_PER_PASS, last));
-        sl.s3 = pf_load_i32(seq_slots + min(key + 3 * KEYS_PER_PASS, last));
-    } else {
-        sl.s2 = sl.s3 = 0;
-    }
+// by wave 0: ids of tile `tile` of a sequence (slot list seq_slots, lkv keys; rows past the end repeat the
+// last key and are masked later) into the 64-int LDS array at `dst`
+__device__ __forceinline__ void pf_fetch_slot_ids(const int32_t* __restrict__ seq_slots, int tile, int lkv, int lane, unsigned dst) {
+    pf_dma4(seq_slots + min(tile * PF_KVBLK + lane, lkv - 1), dst);
 }
-// Wait until at most N of this wave's vector-memory operations are still in flight (they complete in
-// issue order), and tie the slot registers to the wait.
-template <int N>
-__device__ __forceinline__ void pf_wait(PfSlots& sl) {
-    static_assert(N == 0 || N == 4 || N == 8, "vmcnt immediates used here");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(sl.s0), "+v"(sl.s1), "+v"(sl.s2), "+v"(sl.s3) : : "memory");
-}
+// every vector-memory operation of this wave has completed, the copies into LDS included (the compiler
+// does not know of those)
+__device__ __forceinline__ void pf_wait_copies() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 // One row pair (K and V, 256 B each, 16 lanes per row) straight from the pool into LDS, no register
 // staging: a wave instruction writes 64 consecutive 16-byte slots (4 rows) starting at a wave-uniform
 // LDS address, so the swizzle is applied on the global side: the lane that fills position `pos` of row r
 // fetches piece pos ^ swz(r).
 // The copy is issued from inline assembly: through the compiler's builtin every later LDS read is held
 // back until the copy has landed (the compiler cannot tell the two buffers apart), which puts the whole
-// HBM latency in front of every tile.  The waits are therefore explicit: pf_wait<N>() before the barrier
-// that publishes a tile.
+// HBM latency in front of every tile.  The waits are therefore explicit: pf_wait_copies() before the
+// barrier that publishes a tile.
 __device__ __forceinline__ void pf_dma16(const unsigned char* g, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");   // m0 has no other user in this kernel
+    // lds_addr is wave-uniform by construction; the explicit broadcast puts it in a scalar register even
+    // where the compiler cannot prove that.  m0 has no other user in this kernel.
+    const unsigned uni = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(uni) : "memory");
 }
 // LDS reads by 32-bit LDS address (address arithmetic with XOR would hide the address space from the
 // compiler if it were done on generic pointers)
@@ -134,22 +120,23 @@ __device__ __forceinline__ void pf_gather_one(int slot_id, unsigned n_slots, con
     pf_dma16(kbase + off, k_dst);
     pf_dma16(vbase + off, v_dst);
 }
-// k_dst / v_dst: start of this WAVE's four rows of pass 0 in the tile buffer (wave-uniform)
+// ids: LDS address of the tile's 64 slot ids; k_dst / v_dst: start of this WAVE's four rows of pass 0 in
+// the tile buffer (wave-uniform)
+typedef __attribute__((address_space(3))) const int pf_lds_i32;
 template <int PASSES, int KEYS_PER_PASS>
-__device__ __forceinline__ void pf_gather(const PfSlots& sl, unsigned n_slots, const unsigned char* __restrict__ kbase,
+__device__ __forceinline__ void pf_gather(unsigned ids, int krow0, unsigned n_slots, const unsigned char* __restrict__ kbase,
                                           const unsigned char* __restrict__ vbase, unsigned row_bytes,
                                           unsigned k_dst, unsigned v_dst) {
     constexpr int STEP = KEYS_PER_PASS * 256;
-    pf_gather_one(sl.s0, n_slots, kbase, vbase, row_bytes, k_dst, v_dst);
-    pf_gather_one(sl.s1, n_slots, kbase, vbase, row_bytes, k_dst + STEP, v_dst + STEP);
-    if constexpr (PASSES == 4) {
-        pf_gather_one(sl.s2, n_slots, kbase, vbase, row_bytes, k_dst + 2 * STEP, v_dst + 2 * STEP);
-        pf_gather_one(sl.s3, n_slots, kbase, vbase, row_bytes, k_dst + 3 * STEP, v_dst + 3 * STEP);
-    }
+    int id[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) id[p] = *reinterpret_cast<pf_lds_i32*>((uintptr_t)(ids + 4 * (krow0 + p * KEYS_PER_PASS)));
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) pf_gather_one(id[p], n_slots, kbase, vbase, row_bytes, k_dst + p * STEP, v_dst + p * STEP);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G, int NWAVES, int NBUF>
+template <int G, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ qo_indptr,
@@ -162,11 +149,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     constexpr int KEYS_PER_PASS = NT / 16;    // 16 lanes move one 256-byte row
     constexpr int PASSES = PF_KVBLK / KEYS_PER_PASS;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    // NBUF tile buffers of [K: 64 keys x 256 B, pieces swizzled by key & 15][V: same, swizzled by (key & 3) << 2]
+    // two tile buffers of [K: 64 keys x 256 B, pieces swizzled by key & 15][V: same, swizzled by (key & 3) << 2],
+    // two arrays of 64 slot ids, the counters of the owner lookup
     constexpr int BUF_BYTES = 2 * PF_KVBLK * 256;
-    constexpr int DIST = NBUF - 1;            // tiles the row copies run ahead of the computation
-    constexpr int PER_TILE = 2 * PASSES;      // row-copy instructions per wave and tile
-    static_assert(NBUF == 2 || NBUF == 3, "ring of two or three tile buffers");
+    constexpr int IDS_BYTES = 4 * PF_KVBLK;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l32 = lane & 31;
@@ -181,7 +167,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     // of every workgroup's first tile; this is one.)
     // (the counters sit behind the tile buffers: the fragment addressing XORs address bits and needs the
     // buffers at a 256-byte boundary, which a static LDS array in front of them would break)
-    int* owner_count = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
+    int* owner_count = reinterpret_cast<int*>(smem + 2 * BUF_BYTES + 2 * IDS_BYTES);
     int below = 0;
     for (int i = tid; i < batch; i += NT) below += tab[1 + i] <= gblk ? 1 : 0;
 #pragma unroll
@@ -227,10 +213,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     float m_run = -INFINITY, l_run = 0.f;
 
     static_assert(PASSES == 2 || PASSES == 4, "tile gather is written for 256- or 512-thread workgroups");
-    // Pipeline, one barrier per tile, ring of NBUF tile buffers: while tile t is computed, the rows of tiles
-    // t + 1 .. t + DIST travel from the pool into the other buffers and the slot ids of tile t + DIST + 1
-    // into registers.  At the end of tile t the wave waits only until tile t + 1 has landed (operations
-    // complete in issue order, so "all but the youngest PER_TILE" when a further tile is in flight).
+    // Pipeline, one barrier per tile: while tile t is computed from one buffer, the rows of tile t + 1 travel
+    // pool -> LDS into the other and the slot ids of tile t + 2 block table -> LDS.
     const int pos = tid & 15, krow0 = tid >> 4;
     const int32_t* seq_slots = kv_indices + kv0;
     // this lane's piece of a row: KEYS_PER_PASS is a multiple of 16, so the swizzle is the same for every pass
@@ -248,37 +232,27 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         const int pc0 = 2 * (grp & 1) + (tp >> 1);
         return row * 256 + ((pc0 ^ ((row & 3) << 2)) << 4) + 8 * (tp & 1);
     }();
-    PfSlots slots, slots_next;
-    unsigned ring0 = lds0, ring1 = lds0 + BUF_BYTES, ring2 = lds0 + (NBUF - 1) * BUF_BYTES;   // this tile, next, the one after
+    unsigned ring0 = lds0, ring1 = lds0 + BUF_BYTES;                 // tile being computed, tile arriving
+    unsigned ids0 = lds0 + 2 * BUF_BYTES, ids1 = ids0 + IDS_BYTES;     // slot ids of the next tile, of the one after
     if (n_tiles > 0) {
-        pf_load_slots<PASSES, KEYS_PER_PASS>(slots, 0, krow0, lkv, seq_slots);
-        pf_load_slots<PASSES, KEYS_PER_PASS>(slots_next, 1, krow0, lkv, seq_slots);
-        pf_wait<0>(slots);
-        pf_wait<0>(slots_next);
-        pf_gather<PASSES, KEYS_PER_PASS>(slots, n_slots_u, kg, vg, row_bytes, ring0 + wave_rows, ring0 + PF_KVBLK * 256 + wave_rows);
-        if constexpr (DIST == 2) {
-            if (n_tiles > 1) {
-                pf_load_slots<PASSES, KEYS_PER_PASS>(slots, 2, krow0, lkv, seq_slots);   // older than the copies of tile 1
-                pf_gather<PASSES, KEYS_PER_PASS>(slots_next, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
-                pf_wait<PER_TILE>(slots);    // tile 0 and the slot ids of tile 2 are in; tile 1 may still fly
-            } else {
-                pf_wait<0>(slots);
-            }
-        } else {
-            slots = slots_next;
-            pf_wait<0>(slots);
+        if (wave == 0) {
+            pf_fetch_slot_ids(seq_slots, 0, lkv, lane, ids0);
+            if (n_tiles > 1) pf_fetch_slot_ids(seq_slots, 1, lkv, lane, ids1);
         }
+        pf_wait_copies();
+        __syncthreads();
+        pf_gather<PASSES, KEYS_PER_PASS>(ids0, krow0, n_slots_u, kg, vg, row_bytes, ring0 + wave_rows, ring0 + PF_KVBLK * 256 + wave_rows);
+        pf_wait_copies();
     }
     __syncthreads();
-    // invariant at the top of tile t: `slots` holds the ids of tile t + DIST
+    { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
+    // at the top of tile t: ids0 holds the ids of tile t + 1, ids1 is free (its ids were used a tile ago)
     for (int tile = 0; tile < n_tiles; ++tile) {
         const unsigned k_lds = ring0;   // LDS byte addresses
         const unsigned v_lds = k_lds + PF_KVBLK * 256;
-        const bool more = tile + DIST < n_tiles;
-        if (more) {   // its buffer held tile t - 1 (or t + 1 - NBUF): every wave left it before the last barrier
-            const unsigned kn = (DIST == 2 ? ring2 : ring1) + wave_rows;
-            pf_load_slots<PASSES, KEYS_PER_PASS>(slots_next, tile + DIST + 1, krow0, lkv, seq_slots);
-            pf_gather<PASSES, KEYS_PER_PASS>(slots, n_slots_u, kg, vg, row_bytes, kn, kn + PF_KVBLK * 256);
+        if (tile + 1 < n_tiles) {   // the other buffer held tile t - 1: every wave left it before the last barrier
+            pf_gather<PASSES, KEYS_PER_PASS>(ids0, krow0, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
+            if (tile + 2 < n_tiles && wave == 0) pf_fetch_slot_ids(seq_slots, tile + 2, lkv, lane, ids1);
         }
 
         const int key_base = tile * PF_KVBLK;
@@ -387,17 +361,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        if (more) {
-            if constexpr (DIST == 2) pf_wait<PER_TILE>(slots_next); else pf_wait<0>(slots_next);
-            slots = slots_next;
-        } else {
-            pf_wait<0>(slots);
-        }
-        __syncthreads();   // tile + 1 visible; this tile's buffer free
-        {
-            const unsigned t0 = ring0;
-            if constexpr (NBUF == 3) { ring0 = ring1; ring1 = ring2; ring2 = t0; } else { ring0 = ring1; ring1 = t0; ring2 = t0; }
-        }
+        pf_wait_copies();
+        __syncthreads();   // tile + 1 and the ids of tile + 2 visible; this tile's buffer free
+        { const unsigned t0 = ring0; ring0 = ring1; ring1 = t0; }
+        { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
     }
 
     // ---- epilogue: O = O^T / l, one query per lane, dims in registers ----
@@ -432,26 +399,27 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
     const int g = n_q_heads / n_kv_heads;
     const float scale_log2 = sm_scale * PF_LOG2E;
     hipStream_t st = (hipStream_t)stream;
-    const size_t buf_bytes = 2 * PF_KVBLK * 256, tail_bytes = 64;   // tile buffers + per-wave counters
-#define NVX_PF(GG, NW, QPOS, NB)                                                                                       \
+    // two tile buffers of K and V, two tiles of slot ids, per-wave counters
+    const size_t lds_bytes = 2 * 2 * PF_KVBLK * 256 + 2 * 4 * PF_KVBLK + 64;
+#define NVX_PF(GG, NW, QPOS)                                                                                           \
     do {                                                                                                                \
-        static const hipError_t attr = hipFuncSetAttribute((const void*)paged_prefill_kernel<GG, NW, NB>,               \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((NB) * buf_bytes + tail_bytes)); \
-        NVX_REQUIRE(attr == hipSuccess, NVX_ELAUNCH, "nvx_paged_prefill: cannot reserve %d KB of LDS", (int)((NB) * buf_bytes / 1024)); \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)paged_prefill_kernel<GG, NW>,                   \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        NVX_REQUIRE(attr == hipSuccess, NVX_ELAUNCH, "nvx_paged_prefill: cannot reserve %d KB of LDS", (int)(lds_bytes / 1024)); \
         const int64_t blocks = ((n_tokens + (QPOS) - 1) / (QPOS) + batch) * n_kv_heads;                                 \
-        hipLaunchKernelGGL((paged_prefill_kernel<GG, NW, NB>), dim3((unsigned)blocks), dim3((NW) * 64), (NB) * buf_bytes + tail_bytes, st, \
+        hipLaunchKernelGGL((paged_prefill_kernel<GG, NW>), dim3((unsigned)blocks), dim3((NW) * 64), lds_bytes, st,      \
                            (const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache,        \
                            n_slots, qo_indptr, kv_indptr, kv_indices, plan_ws, (uint16_t*)out, (int)batch, n_kv_heads,  \
                            scale_log2);                                                                                 \
     } while (0)
     switch (g) {
-        case 1: NVX_PF(1, 4, 128, 2); break;
+        case 1: NVX_PF(1, 4, 128); break;
         // two 4-wave workgroups per CU (each in its own phase of the tile loop) measured faster than one
         // 8-wave workgroup of 128 queries (0.75 vs 0.86 ms on the bench prompts); a third tile buffer (row
         // copies two tiles ahead) changed neither
-        case 2: NVX_PF(2, 4, 64, 2); break;
-        case 4: NVX_PF(4, 4, 32, 2); break;
-        case 8: NVX_PF(8, 8, 32, 2); break;
+        case 2: NVX_PF(2, 4, 64); break;
+        case 4: NVX_PF(4, 4, 32); break;
+        case 8: NVX_PF(8, 8, 32); break;
         default: return nvx_fail(NVX_EUNSUPPORTED, "nvx_paged_prefill: query/kv head ratio %d not in {1,2,4,8}", g);
     }
 #undef NVX_PF
