@@ -123,27 +123,42 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
     const int row = blockIdx.x;
     const int64_t split_stride = (int64_t)rows * hidden;
     float v[SLABS][4];
+    uint2 wv[SLABS];
     float ss = 0.f;
+    // The kernel is a chain of memory round trips and little else, so every load of a slab (up to four
+    // splits at a time, the residual, the weight) is issued before the first use.  With a plain loop over
+    // the splits the compiler waited for each load before issuing the next: six round trips in a row.
 #pragma unroll
     for (int it = 0; it < SLABS; ++it) {
         const int col = it * 1024 + tid * 4;
         if (col < hidden) {
             const float* p = partials + (int64_t)row * hidden + col;
-            float4 a = *reinterpret_cast<const float4*>(p);
-            for (int s = 1; s < n_splits; ++s) {
-                const float4 b = *reinterpret_cast<const float4*>(p + s * split_stride);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            uint2 r = make_uint2(0u, 0u);
+            if (HAS_RES) r = *reinterpret_cast<const uint2*>(residual + (int64_t)row * hidden + col);
+            wv[it] = *reinterpret_cast<const uint2*>(weight + col);
+            nvx_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < n_splits; s0 += 4) {
+                nvx_f32x4 b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // splits past the end re-read split 0 (cached) and are not added
+                    const int sidx = s0 + j < n_splits ? s0 + j : 0;
+                    b[j] = *reinterpret_cast<const nvx_f32x4*>(p + sidx * split_stride);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // same order of additions as a loop over the splits
+                    if (s0 + j == 0) a = b[j];
+                    else if (s0 + j < n_splits) a += b[j];
+                }
             }
             if (HAS_RES) {
-                const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)row * hidden + col);
-                v[it][0] = round_bf16(a.x) + bf16lo_to_f32(r.x);
-                v[it][1] = round_bf16(a.y) + bf16hi_to_f32(r.x);
-                v[it][2] = round_bf16(a.z) + bf16lo_to_f32(r.y);
-                v[it][3] = round_bf16(a.w) + bf16hi_to_f32(r.y);
+                v[it][0] = round_bf16(a[0]) + bf16lo_to_f32(r.x);
+                v[it][1] = round_bf16(a[1]) + bf16hi_to_f32(r.x);
+                v[it][2] = round_bf16(a[2]) + bf16lo_to_f32(r.y);
+                v[it][3] = round_bf16(a[3]) + bf16hi_to_f32(r.y);
                 *reinterpret_cast<uint2*>(residual_out + (int64_t)row * hidden + col) =
                     make_uint2(pack_bf16x2(v[it][0], v[it][1]), pack_bf16x2(v[it][2], v[it][3]));
             } else {
-                v[it][0] = round_bf16(a.x); v[it][1] = round_bf16(a.y); v[it][2] = round_bf16(a.z); v[it][3] = round_bf16(a.w);
+                v[it][0] = round_bf16(a[0]); v[it][1] = round_bf16(a[1]); v[it][2] = round_bf16(a[2]); v[it][3] = round_bf16(a[3]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) ss += v[it][j] * v[it][j];
@@ -158,10 +173,9 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
     for (int it = 0; it < SLABS; ++it) {
         const int col = it * 1024 + tid * 4;
         if (col < hidden) {
-            const uint2 wv = *reinterpret_cast<const uint2*>(weight + col);
             *reinterpret_cast<uint2*>(y + (int64_t)row * hidden + col) =
-                make_uint2(pack_bf16x2((v[it][0] * inv) * bf16lo_to_f32(wv.x), (v[it][1] * inv) * bf16hi_to_f32(wv.x)),
-                           pack_bf16x2((v[it][2] * inv) * bf16lo_to_f32(wv.y), (v[it][3] * inv) * bf16hi_to_f32(wv.y)));
+                make_uint2(pack_bf16x2((v[it][0] * inv) * bf16lo_to_f32(wv[it].x), (v[it][1] * inv) * bf16hi_to_f32(wv[it].x)),
+                           pack_bf16x2((v[it][2] * inv) * bf16lo_to_f32(wv[it].y), (v[it][3] * inv) * bf16hi_to_f32(wv[it].y)));
         }
     }
 }
