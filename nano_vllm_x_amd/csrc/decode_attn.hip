@@ -425,25 +425,40 @@ __global__ __launch_bounds__(256, (G <= 2 ? 4 : 2)) void paged_decode_kernel(
 // then the chunks' partials, all independent, folded in one pass.
 __global__ __launch_bounds__(128) void decode_merge_kernel(const int32_t* __restrict__ plan, const float* __restrict__ partial,
                                                            uint16_t* __restrict__ out, int hq_total, int batch, int max_items) {
+    // the grid is exactly batch x hq_total blocks
     const int b = blockIdx.x / hq_total, hq = blockIdx.x % hq_total;
-    if (b >= batch) return;
-    const int2 info = *reinterpret_cast<const int2*>(plan + 8 + (int64_t)DEC_REC_INTS * max_items + 2 * b);
-    const int first = info.x, nch = info.y;
+    // (first item, chunk count) in ONE 8-byte load: as two fields the compiler fetched the count, tested
+    // it, and only then fetched the other
+    const unsigned long long info =
+        *reinterpret_cast<const unsigned long long*>(plan + 8 + (int64_t)DEC_REC_INTS * max_items + 2 * b);
+    const int first = (int)(unsigned)(info & 0xffffffffull), nch = (int)(unsigned)(info >> 32);
     if (nch <= 1) return;
     const int d = threadIdx.x;
     const float* base = partial + ((int64_t)first * hq_total + hq) * DEC_PART_STRIDE;
     const int64_t step = (int64_t)hq_total * DEC_PART_STRIDE;
     float mall = -INFINITY, lsum = 0.f, o = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < nch; ++i) {
-        const float* p = base + i * step;
-        const float mi = p[128], li = p[129], ai = p[d];
-        const float mnew = fmaxf(mall, mi);
-        const float mref = mnew == -INFINITY ? 0.f : mnew;
-        const float so = __builtin_amdgcn_exp2f(mall - mref), sn = __builtin_amdgcn_exp2f(mi - mref);
-        lsum = lsum * so + li * sn;
-        o = o * so + ai * sn;
-        mall = mnew;
+    // eight chunks per round trip (sequences rarely have more at serving batch sizes): chunks past the end
+    // re-read the last one and are not folded in
+    for (int i0 = 0; i0 < nch; i0 += 8) {
+        float mi[8], li[8], ai[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = i0 + j < nch;
+            const float* p = base + (live ? i0 + j : nch - 1) * step;
+            // an empty chunk (m = -inf, l = 0, acc = 0) folds in as a no-op, so the fold below has no branches
+            // (with branches the compiler moved every load into its branch: one round trip per chunk)
+            const float pm = p[128], pl = p[129], pa = p[d];
+            mi[j] = live ? pm : -INFINITY; li[j] = live ? pl : 0.f; ai[j] = live ? pa : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float mnew = fmaxf(mall, mi[j]);
+            const float mref = mnew == -INFINITY ? 0.f : mnew;
+            const float so = __builtin_amdgcn_exp2f(mall - mref), sn = __builtin_amdgcn_exp2f(mi[j] - mref);
+            lsum = lsum * so + li[j] * sn;
+            o = o * so + ai[j] * sn;
+            mall = mnew;
+        }
     }
     out[((int64_t)b * hq_total + hq) * 128 + d] = f32_to_bf16bits(lsum > 0.f ? o / lsum : 0.f);
 }
