@@ -418,7 +418,7 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
         // 8-wave workgroup of 128 queries (0.75 vs 0.86 ms on the bench prompts); a third tile buffer (row
         // copies two tiles ahead) changed neither
         case 2: NVX_PF(2, 4, 64); break;
-        case 4: NVX_PF(4, 4, 32); break;
+        case 4: NVX_PF(4, 4, 32); break;   // 8 waves / 64 queries measured slower here too (1.77 vs 1.57 ms at 32 q heads)
         case 8: NVX_PF(8, 8, 32); break;
         default: return nvx_fail(NVX_EUNSUPPORTED, "nvx_paged_prefill: query/kv head ratio %d not in {1,2,4,8}", g);
     }

@@ -122,6 +122,9 @@ def cmd_decode(args):
 
 
 def cmd_prefill(args):
+    global HQ, HKV
+    if args.heads:
+        HQ, HKV = (int(x) for x in args.heads.split(","))
     prompts, _ = bench.workload(args.num_seqs)
     lens = [len(p) for p in prompts]
     if args.uniform_len:   # every sequence the same length: separates steady-state rate from per-workgroup overheads
@@ -214,5 +217,6 @@ if __name__ == "__main__":
     ap.add_argument("--hkv1", action="store_true")
     ap.add_argument("--qkv", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0)
+    ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
     {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "linear": cmd_linear}[a.cmd](a)
