@@ -17,10 +17,14 @@ from .scheduler import Scheduler
 
 class EngineCore:
     def __init__(self, kv_cache_size: int, max_bs: int, context_len: int = 2048, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None):
+                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False):
         self.context_len = context_len
         self.prefix_reuse = prefix_reuse
         self.max_prefill_tokens = max_prefill_tokens
+        # The reference has no stop rule tied to the context length: a request without max_tokens and with
+        # ignore_eos runs until the pool is exhausted.  Opt-in: finish with LENGTH once a sequence is
+        # context_len tokens long (default off = the reference's rules only).
+        self.stop_at_context_len = stop_at_context_len
         self.scheduler = Scheduler(kv_cache_size=kv_cache_size, max_bs=max_bs, prefix_reuse=prefix_reuse,
                                    max_prefill_tokens=max_prefill_tokens)
 
@@ -39,16 +43,17 @@ class EngineCore:
     def has_unfinished_sequences(self) -> bool:
         return self.scheduler.has_unfinished_sequences()
 
-    @staticmethod
-    def _is_sequence_finished(seq: Sequence):
+    def _is_sequence_finished(self, seq: Sequence):
         """Stop rules in the reference's order (engine.py:143-154).  NB `max_tokens` caps the TOTAL
-        length, prompt included."""
+        length, prompt included.  The optional context-length rule comes last."""
         sp = seq.sampling_params
         if not sp.ignore_eos and seq.token_ids[-1] == sp.eos_token_id:
             return True, FinishReason.STOP
         if sp.max_tokens and seq.num_tokens >= sp.max_tokens:
             return True, FinishReason.LENGTH
         if sp.max_new_tokens and seq.num_tokens >= seq.prompt_len + sp.max_new_tokens:
+            return True, FinishReason.LENGTH
+        if self.stop_at_context_len and seq.num_tokens >= self.context_len:
             return True, FinishReason.LENGTH
         return False, None
 
@@ -71,7 +76,7 @@ class Engine(EngineCore):
     def __init__(self, model: str, gpu_memory_utilization: float, max_bs: int, tp_size: int = 1, pp_size: int = 1,
                  nccl_port: int = 29500, device_ids: Optional[list] = None, enforce_eager: bool = False,
                  context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None):
+                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False):
         from .model_runner import ModelRunner
 
         if pp_size != 1:
@@ -85,7 +90,7 @@ class Engine(EngineCore):
         self.kv_cache_size = kv_cache_size
         self.model_runner.initialize_kv_cache(kv_cache_size)
         super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len, prefix_reuse=prefix_reuse,
-                         max_prefill_tokens=max_prefill_tokens)
+                         max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len)
         self.scheduler.on_release = self.model_runner.release_sequence
         self._inflight = None
 

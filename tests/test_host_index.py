@@ -106,3 +106,25 @@ def test_prefill_token_budget_is_opt_in_and_never_starves():
     capped = prefill_batches(100)
     assert capped == [[30, 50, 10], [200], [5, 5]]          # FCFS order kept; the 200-token prompt runs alone
     assert all(sum(b) <= 100 or len(b) == 1 for b in capped)
+
+
+def test_context_length_stop_rule_is_opt_in():
+    """EngineCore(stop_at_context_len=True) ends a sequence with LENGTH at context_len tokens; off (default)
+    only the reference's rules apply (engine.py:143-154 has no such rule)."""
+    from nano_vllm_x_amd.core.common import FinishReason, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    def run(flag):
+        core = EngineCore(kv_cache_size=400, max_bs=4, context_len=16, stop_at_context_len=flag)
+        core.add_sequence("a", list(range(10)), SamplingParams(ignore_eos=True, max_new_tokens=20))
+        core.add_sequence("b", list(range(40)), SamplingParams(ignore_eos=True, max_new_tokens=3))   # prompt cut to its last 16 tokens
+        ends = {}
+        while core.has_unfinished_sequences():
+            b = core.scheduler.schedule()
+            for o in core.update_from_output(b, [1] * b.num_seqs):
+                if o.is_finished:
+                    ends[o.seq_id] = (o.num_prompt_tokens + o.num_generated_tokens, o.finish_reason)
+        return ends
+
+    assert run(False) == {"a": (30, FinishReason.LENGTH), "b": (19, FinishReason.LENGTH)}
+    assert run(True) == {"a": (16, FinishReason.LENGTH), "b": (17, FinishReason.LENGTH)}   # b: one token, then at the limit
