@@ -286,6 +286,17 @@ def test_prefill_attention_bench_like(ops):
     _prefill_case(ops, 42, lens, lens, 16, 8, check_oracle=False)
 
 
+def test_prefill_many_short_sequences(ops):
+    """More sequences than threads in a workgroup (the owner lookup walks the plan table in several
+    passes), empty sequences in between, queries shorter than their key lists."""
+    rng = np.random.default_rng(7)
+    q_lens = [int(x) for x in rng.integers(0, 40, size=700)]
+    q_lens[0], q_lens[-1] = 0, 0
+    kv_lens = [q + int(x) if q else 0 for q, x in zip(q_lens, rng.integers(0, 30, size=700))]
+    _prefill_case(ops, 44, q_lens, kv_lens, 16, 8)
+    _prefill_case(ops, 45, q_lens[:300], kv_lens[:300], 8, 2)
+
+
 def test_prefill_matches_oracle_long_rows(ops):
     _prefill_case(ops, 43, [1024, 517], [1024, 517], 16, 8)
 
