@@ -338,8 +338,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         read_group(1);
         __builtin_amdgcn_sched_barrier(0);
         nvx_bf16x8 pf[4];
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
+        auto probabilities = [&](int gi) {   // P^T of 16 keys: 8 exponentials per lane
             const int kb = gi >> 1, s2 = gi & 1;
             uint32_t w[4];
 #pragma unroll
@@ -350,14 +349,25 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
                 w[j] = pack_bf16x2(p0, p1);
             }
             pf[gi] = __builtin_bit_cast(nvx_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-        }
+        };
+        probabilities(0);
         __builtin_amdgcn_sched_barrier(0);
+        // the four MFMAs of a group run on the matrix pipe while the vector ALU makes the next group's
+        // probabilities: one MFMA, then a share of the exponentials, four times over
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
                 o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, vf[gi][d]), pf[gi], o_acc[d], 0, 0, 0);
+            if (gi + 1 < 4) probabilities(gi + 1);
             if (gi + 2 < 4) read_group(gi + 2);
+            if (gi + 1 < 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         }
