@@ -241,7 +241,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         }
         pf_wait_copies();
         __syncthreads();
+        // the first TWO tiles travel together: a workgroup's first round trip to the pool is the one nothing
+        // can hide, so it carries as much as the buffers hold
         pf_gather<PASSES, KEYS_PER_PASS>(ids0, krow0, n_slots_u, kg, vg, row_bytes, ring0 + wave_rows, ring0 + PF_KVBLK * 256 + wave_rows);
+        if (n_tiles > 1)
+            pf_gather<PASSES, KEYS_PER_PASS>(ids1, krow0, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
         pf_wait_copies();
     }
     __syncthreads();
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         const unsigned k_lds = ring0;   // LDS byte addresses
         const unsigned v_lds = k_lds + PF_KVBLK * 256;
         if (tile + 1 < n_tiles) {   // the other buffer held tile t - 1: every wave left it before the last barrier
-            pf_gather<PASSES, KEYS_PER_PASS>(ids0, krow0, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
+            if (tile > 0)           // (tile 1 came with tile 0)
+                pf_gather<PASSES, KEYS_PER_PASS>(ids0, krow0, n_slots_u, kg, vg, row_bytes, ring1 + wave_rows, ring1 + PF_KVBLK * 256 + wave_rows);
             if (tile + 2 < n_tiles && wave == 0) pf_fetch_slot_ids(seq_slots, tile + 2, lkv, lane, ids1);
         }
 
