@@ -382,20 +382,38 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
     }
 
-    // ---- epilogue: O = O^T / l, one query per lane, dims in registers ----
+    // ---- epilogue: O = O^T / l ----
+    // A lane holds 64 of the 128 dims of ONE query row, so stores straight from registers are 64 scattered
+    // 8-byte writes per instruction (a third of the kernel's time on short sequences).  Each wave instead
+    // turns its 32 x 128 block around in LDS (the tile buffers are free: the loop ended with a barrier;
+    // rows 272 B apart keep the 8-byte writes off each other's banks and the 16-byte reads aligned) and
+    // stores whole 256-byte rows, four per instruction.
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (q_ok) {
+    {
+        constexpr int ROW = 272;
+        const unsigned stage = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave * 32 * ROW);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        uint16_t* orow = out + ((int64_t)(q0 + qi) * hq_total + hq) * 128;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) u32x2 lds_u2;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int dim = d * 32 + 8 * r4 + 4 * half;
-                *reinterpret_cast<uint2*>(orow + dim) =
-                    make_uint2(pack_bf16x2(o_acc[d][4 * r4] * inv, o_acc[d][4 * r4 + 1] * inv),
-                               pack_bf16x2(o_acc[d][4 * r4 + 2] * inv, o_acc[d][4 * r4 + 3] * inv));
+                *reinterpret_cast<lds_u2*>((uintptr_t)(stage + l32 * ROW + dim * 2)) =
+                    u32x2{pack_bf16x2(o_acc[d][4 * r4] * inv, o_acc[d][4 * r4 + 1] * inv),
+                          pack_bf16x2(o_acc[d][4 * r4 + 2] * inv, o_acc[d][4 * r4 + 3] * inv)};
             }
+        // a wave's LDS operations complete in order: no barrier between its writes and its reads
+        const int rq = lane >> 4, pc = lane & 15;
+        const int q_first = qb * QPOS + pb * 32;   // the wave's first query position
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + rq;
+            const nvx_u32x4 v = pf_lds_read16(stage + row * ROW + pc * 16);
+            if (q_first + row < lq)
+                *reinterpret_cast<nvx_u32x4*>(out + ((int64_t)(q0 + q_first + row) * hq_total + hq) * 128 + pc * 8) = v;
+        }
     }
 }
 
@@ -414,10 +432,12 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
     const int g = n_q_heads / n_kv_heads;
     const float scale_log2 = sm_scale * PF_LOG2E;
     hipStream_t st = (hipStream_t)stream;
-    // two tile buffers of K and V, two tiles of slot ids, per-wave counters
-    const size_t lds_bytes = 2 * 2 * PF_KVBLK * 256 + 2 * 4 * PF_KVBLK + 64;
+    // two tile buffers of K and V, two tiles of slot ids, per-wave counters; at the end the same memory
+    // stages the output, 32 rows of 272 B per wave
+    const size_t loop_bytes = 2 * 2 * PF_KVBLK * 256 + 2 * 4 * PF_KVBLK + 64;
 #define NVX_PF(GG, NW, QPOS)                                                                                           \
     do {                                                                                                                \
+        const size_t lds_bytes = loop_bytes > (size_t)(NW) * 32 * 272 ? loop_bytes : (size_t)(NW) * 32 * 272;           \
         static const hipError_t attr = hipFuncSetAttribute((const void*)paged_prefill_kernel<GG, NW>,                   \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
         NVX_REQUIRE(attr == hipSuccess, NVX_ELAUNCH, "nvx_paged_prefill: cannot reserve %d KB of LDS", (int)(lds_bytes / 1024)); \
