@@ -184,7 +184,7 @@ def cmd_linear(args):
     import torch.nn.functional as F
     shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up+silu", 6144, 1024, 1), ("down", 1024, 3072, 2)]
     layers = 28
-    for m in (1, 8, 29, 64, 123, 256):
+    for m in ((int(os.environ["NVX_BENCH_M"]),) if os.environ.get("NVX_BENCH_M") else (1, 8, 29, 64, 123, 256)):
         for name, n, k, mode in shapes:
             ws = [(torch.randn(n, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(layers)]
             x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
