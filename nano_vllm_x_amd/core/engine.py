@@ -17,7 +17,7 @@ from .scheduler import Scheduler
 
 class EngineCore:
     def __init__(self, kv_cache_size: int, max_bs: int, context_len: int = 2048, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False):
+                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False):
         self.context_len = context_len
         self.prefix_reuse = prefix_reuse
         self.max_prefill_tokens = max_prefill_tokens
@@ -25,8 +25,9 @@ class EngineCore:
         # ignore_eos runs until the pool is exhausted.  Opt-in: finish with LENGTH once a sequence is
         # context_len tokens long (default off = the reference's rules only).
         self.stop_at_context_len = stop_at_context_len
+        self.chunked_prefill = chunked_prefill
         self.scheduler = Scheduler(kv_cache_size=kv_cache_size, max_bs=max_bs, prefix_reuse=prefix_reuse,
-                                   max_prefill_tokens=max_prefill_tokens)
+                                   max_prefill_tokens=max_prefill_tokens, chunked_prefill=chunked_prefill)
 
     def add_sequence(self, sequence_id: str, prompt_token_ids: list, sampling_params: SamplingParams):
         if len(prompt_token_ids) > self.context_len:   # keep the tail (engine.py:59-60)
@@ -62,6 +63,9 @@ class EngineCore:
         sched = self.scheduler
         update, finished, finish = sched.update_sequence, self._is_sequence_finished, sched.finish_sequence
         for seq, tok in zip(batch.seqs, output_ids):
+            if getattr(seq, "partial_of", None) is not None:   # a chunk that stops before the prompt does: no token yet
+                sched.finish_chunk(seq)
+                continue
             update(seq, tok)
             done, why = finished(seq)
             if done:
@@ -76,7 +80,7 @@ class Engine(EngineCore):
     def __init__(self, model: str, gpu_memory_utilization: float, max_bs: int, tp_size: int = 1, pp_size: int = 1,
                  nccl_port: int = 29500, device_ids: Optional[list] = None, enforce_eager: bool = False,
                  context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False):
+                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False):
         from .model_runner import ModelRunner
 
         if pp_size != 1:
@@ -90,7 +94,8 @@ class Engine(EngineCore):
         self.kv_cache_size = kv_cache_size
         self.model_runner.initialize_kv_cache(kv_cache_size)
         super().__init__(kv_cache_size=kv_cache_size, max_bs=max_bs, context_len=context_len, prefix_reuse=prefix_reuse,
-                         max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len)
+                         max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len,
+                         chunked_prefill=chunked_prefill)
         self.scheduler.on_release = self.model_runner.release_sequence
         self._inflight = None
 
@@ -129,7 +134,7 @@ class Engine(EngineCore):
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
         self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse,
-                                   max_prefill_tokens=self.max_prefill_tokens)
+                                   max_prefill_tokens=self.max_prefill_tokens, chunked_prefill=self.chunked_prefill)
         self.scheduler.on_release = self.model_runner.release_sequence
 
     def wait_until_ready(self):

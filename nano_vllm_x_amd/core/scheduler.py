@@ -21,6 +21,14 @@ One addition, off by default: `prefix_reuse=True` consults the radix tree when a
 cached prefix).  The matched prefix's slots become the head of the sequence's block table, the prefill
 computes only the rest, and the slot accounting at finish/preemption distinguishes shared from owned
 slots.  With the flag off every decision is the reference's.
+
+A second addition, also off by default: `chunked_prefill=True` (with `max_prefill_tokens`) lets a prompt
+that does not fit the step's token budget be computed over several prefill steps.  The sequence holds all
+its slots from admission (as every admitted sequence does here); a chunk step presents a truncated copy of
+it to the model -- tokens and slots up to the chunk's end, `cached_kv_len` at the chunk's start -- so the
+prefill path that serves cached prefixes computes exactly that range, and the token the model samples for
+a truncated copy is dropped.  The last chunk is an ordinary prefill of the real sequence.  Chunks do not
+mix with decode rows (the policy stays prefill-first).
 """
 from __future__ import annotations
 
@@ -33,7 +41,7 @@ from .kv_cache import KVCacheManager
 
 class Scheduler:
     def __init__(self, kv_cache_size: int, max_bs: int = 32, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None):
+                 max_prefill_tokens: Optional[int] = None, chunked_prefill: bool = False):
         self.kv_cache_size = kv_cache_size
         self.max_bs = max_bs
         self.prefix_reuse = prefix_reuse
@@ -42,6 +50,10 @@ class Scheduler:
         # behaviour; with a cap, admission stops before the step would exceed it (one sequence is always
         # admitted, however long).
         self.max_prefill_tokens = max_prefill_tokens
+        if chunked_prefill and not max_prefill_tokens:
+            raise ValueError("chunked_prefill needs max_prefill_tokens (the size of a chunk step)")
+        self.chunked_prefill = chunked_prefill
+        self.prefilling: dict = {}             # seq_id -> sequence whose prompt is only partly computed (admission order)
         self.sequences: dict = {}
         self.waiting: Deque[Sequence] = deque()
         self.running: Deque[Sequence] = deque()
@@ -78,6 +90,12 @@ class Scheduler:
 
     # -- one step ---------------------------------------------------------------------------------
     def schedule(self) -> Optional[ForwardBatch]:
+        if self.chunked_prefill:
+            picked = self._schedule_chunks()
+            if picked:
+                return ForwardBatch(forward_mode=ForwardMode.PREFILL, num_seqs=len(picked), seqs=picked)
+            if self.prefilling:
+                return None                    # every partly computed prompt is in flight
         picked = self._admit_waiting()
         if picked:
             return ForwardBatch(forward_mode=ForwardMode.PREFILL, num_seqs=len(picked), seqs=picked)
@@ -116,6 +134,64 @@ class Scheduler:
             self.running.append(seq)
             self.scheduled.add(seq.seq_id)
         return picked
+
+    # -- chunked prefill -----------------------------------------------------------------------------
+    @staticmethod
+    def _chunk_view(seq: Sequence, end: int) -> Sequence:
+        """What the model is shown for a chunk that stops before the prompt does: the sequence cut at `end`."""
+        view = Sequence(seq_id=seq.seq_id, status=SequenceStatus.RUNNING, num_tokens=end, prompt_len=seq.prompt_len,
+                        token_ids=seq.token_ids[:end], sampling_params=seq.sampling_params, kv_indices=seq.kv_indices[:end],
+                        cached_kv_len=seq.cached_kv_len)
+        view.partial_of = seq
+        return view
+
+    def _schedule_chunks(self):
+        """One prefill step of at most max_prefill_tokens computed tokens: first the next chunks of prompts
+        already under way, then new admissions, the last of which may itself be cut."""
+        budget = self.max_prefill_tokens
+        picked = []
+        for seq in list(self.prefilling.values()):
+            if budget <= 0 or len(picked) >= self.max_bs:
+                break
+            if seq.seq_id in self.scheduled:
+                continue
+            left = len(seq.token_ids) - seq.cached_kv_len
+            take = min(left, budget)
+            budget -= take
+            self.scheduled.add(seq.seq_id)
+            picked.append(seq if take == left else self._chunk_view(seq, seq.cached_kv_len + take))
+        while self.waiting and len(picked) < self.max_bs and budget > 0:
+            seq = self.waiting.popleft()
+            try:
+                if self.prefix_reuse and not seq.kv_indices:
+                    self.kv_manager.adopt_cached_prefix(seq)
+                self.alloc_kv_slots(seq)
+            except RuntimeError:
+                if self.prefix_reuse:
+                    self.kv_manager.release_sequence(seq)
+                self.waiting.appendleft(seq)
+                if not picked and not self.running:
+                    raise
+                break
+            seq.status = SequenceStatus.RUNNING
+            self.running.append(seq)
+            self.scheduled.add(seq.seq_id)
+            left = len(seq.token_ids) - seq.cached_kv_len
+            take = min(left, budget)
+            budget -= take
+            if take == left:
+                picked.append(seq)
+            else:
+                self.prefilling[seq.seq_id] = seq
+                picked.append(self._chunk_view(seq, seq.cached_kv_len + take))
+        return picked
+
+    def finish_chunk(self, view: Sequence):
+        """A chunk step has run: the rows up to the view's end are written; the sampled token is dropped."""
+        seq = view.partial_of
+        self.scheduled.discard(seq.seq_id)
+        if seq.status == SequenceStatus.RUNNING and seq.seq_id in self.prefilling:
+            seq.cached_kv_len = len(view.token_ids)
 
     def _extend_running(self):
         """One more slot for every running sequence not already in flight (scheduler.py:82-115)."""
@@ -160,6 +236,7 @@ class Scheduler:
     def _preempt_detached(self, seq: Sequence):
         """Preempt a sequence that has already been taken off `running`."""
         self.scheduled.discard(seq.seq_id)
+        self.prefilling.pop(seq.seq_id, None)
         self.free_kv_slots(seq)
         seq.status = SequenceStatus.WAITING
         self.waiting.appendleft(seq)
@@ -179,6 +256,8 @@ class Scheduler:
         if seq.status != SequenceStatus.RUNNING:
             return
         self.scheduled.remove(seq.seq_id)
+        if self.prefilling:
+            self.prefilling.pop(seq.seq_id, None)   # its last chunk has run
         seq.cached_kv_len = len(seq.kv_indices)
         seq.token_ids.append(new_token_id)
         seq.num_tokens = len(seq.token_ids)
@@ -193,7 +272,16 @@ class Scheduler:
             self.running.remove(seq)
             self.scheduled.discard(seq.seq_id)
         seq.status = SequenceStatus.FINISHED
-        if self.prefix_reuse:
+        if self.prefilling.pop(seq.seq_id, None) is not None:
+            # aborted with its prompt only partly computed: the rows past cached_kv_len hold nothing, so the
+            # sequence gives its slots back instead of entering the prefix tree
+            if self.prefix_reuse:
+                self.kv_manager.release_sequence(seq)
+            else:
+                self.kv_manager.free_slots(seq.kv_indices)
+                seq.kv_indices.clear()
+                seq.cached_kv_len = 0
+        elif self.prefix_reuse:
             self.kv_manager.cache_sequence_shared(seq)
         else:
             self.kv_manager.cache_sequence(seq)

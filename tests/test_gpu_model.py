@@ -162,6 +162,38 @@ def test_prefix_reuse_generates_the_same_tokens_with_fewer_prefill_rows():
     assert results[True][1] == results[False][1] - 6 * 24
 
 
+def test_chunked_prefill_generates_the_same_tokens():
+    """Scheduler(chunked_prefill=True, max_prefill_tokens=...): prompts longer than the budget are computed
+    over several prefill steps (the later chunks attend to the rows the earlier ones wrote).  The streams of
+    arg-max tokens must equal those of the one-step prefill (arg-max of the logits, not the sampler with
+    top_k = 1: that keeps ties, which bf16 logits of a tiny random model have, and breaks them by a draw that
+    depends on the row's place in the batch)."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    rng = np.random.default_rng(2)
+    requests = [(f"c{i}", rng.integers(0, 256, size=int(n)).tolist(), int(rng.integers(3, 7))) for i, n in enumerate((50, 7, 33, 61, 12))]
+    results = {}
+    for chunked in (False, True):
+        runner, _ = _tiny_runner(enforce_eager=False, max_bs=8, kv_slots=600, context_len=64)
+        core = EngineCore(kv_cache_size=600, max_bs=8, context_len=64, max_prefill_tokens=24 if chunked else None,
+                          chunked_prefill=chunked)
+        core.scheduler.on_release = runner.release_sequence
+        for sid, prompt, n in requests:
+            core.add_sequence(sid, list(prompt), SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=n))
+        got, prefill_steps = {}, 0
+        while core.has_unfinished_sequences():
+            batch = core.scheduler.schedule()
+            prefill_steps += batch.forward_mode == ForwardMode.PREFILL
+            toks = runner.compute_logits(batch).float().argmax(dim=-1).tolist()
+            for o in core.update_from_output(batch, toks):
+                got.setdefault(o.seq_id, []).append(o.new_token_id)
+        results[chunked] = (got, prefill_steps)
+    assert results[True][0] == results[False][0]
+    assert results[False][1] == 1 and results[True][1] == 7      # 163 prompt tokens in steps of at most 24
+    assert all(len(results[True][0][sid]) == n for sid, _, n in requests)
+
+
 def test_decode_projections_fused_path_matches_library_gemm_path():
     """A mid-size Qwen3 (hidden 512) whose decode projections qualify for ops.linear_decode (+ fused
     SiluAndMul, + K-split partials summed inside RMSNorm) against the same model with every projection a

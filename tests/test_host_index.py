@@ -128,3 +128,63 @@ def test_context_length_stop_rule_is_opt_in():
 
     assert run(False) == {"a": (30, FinishReason.LENGTH), "b": (19, FinishReason.LENGTH)}
     assert run(True) == {"a": (16, FinishReason.LENGTH), "b": (17, FinishReason.LENGTH)}   # b: one token, then at the limit
+
+
+def test_chunked_prefill_computes_every_token_once_and_keeps_order():
+    """Scheduler(chunked_prefill=True): a prompt larger than the step budget is computed over several
+    prefill steps; every prompt token is computed exactly once, a cut prompt yields no token until its last
+    chunk, decode steps wait for prompts under way, and the final streams have the lengths asked for."""
+    from nano_vllm_x_amd.core.common import ForwardMode, SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    lens = [30, 250, 10, 120]
+    core = EngineCore(kv_cache_size=2000, max_bs=8, max_prefill_tokens=100, chunked_prefill=True)
+    for i, n in enumerate(lens):
+        # disjoint token ranges: sequences that share a prefix leak their duplicate slots at finish (a quirk of
+        # the reference that is reproduced), which would blur the slot count at the end
+        core.add_sequence(f"s{i}", list(range(1000 * i, 1000 * i + n)), SamplingParams(ignore_eos=True, max_new_tokens=3))
+    computed = {f"s{i}": [] for i in range(len(lens))}
+    steps, outs = [], {f"s{i}": 0 for i in range(len(lens))}
+    while core.has_unfinished_sequences():
+        b = core.scheduler.schedule()
+        assert b is not None
+        if b.forward_mode == ForwardMode.PREFILL:
+            sizes = [len(s.token_ids) - s.cached_kv_len for s in b.seqs]
+            assert sum(sizes) <= 100
+            for s, n in zip(b.seqs, sizes):
+                assert len(s.kv_indices) == len(s.token_ids)          # what the model is shown is self-consistent
+                computed[s.seq_id].append((s.cached_kv_len, s.cached_kv_len + n))
+            steps.append(sizes)
+        else:
+            assert not core.scheduler.prefilling                       # no decode while a prompt is under way
+        for o in core.update_from_output(b, [100000 + len(steps)] * b.num_seqs):
+            outs[o.seq_id] += 1
+    assert steps[:4] == [[30, 70], [100], [80, 10, 10], [100]] and steps[4] == [10]
+    for i, n in enumerate(lens):
+        spans = computed[f"s{i}"]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert outs[f"s{i}"] == 3
+    assert len(core.scheduler.kv_manager.kv_cache_allocator.free_slots) + _slots_in_tree(core.scheduler.kv_manager) == 2000
+
+
+def _slots_in_tree(mgr):
+    total, stack = 0, [mgr.radix_tree.root]
+    while stack:
+        node = stack.pop()
+        total += len(node.value)
+        stack.extend(node.children.values())
+    return total
+
+
+def test_chunked_prefill_abort_midway_returns_every_slot():
+    from nano_vllm_x_amd.core.common import SamplingParams
+    from nano_vllm_x_amd.core.engine import EngineCore
+
+    core = EngineCore(kv_cache_size=500, max_bs=4, max_prefill_tokens=64, chunked_prefill=True)
+    core.add_sequence("a", list(range(200)), SamplingParams(ignore_eos=True, max_new_tokens=2))
+    b = core.scheduler.schedule()
+    core.update_from_output(b, [1])
+    assert core.scheduler.prefilling and core.scheduler.sequences["a"].cached_kv_len == 64
+    core.abort_sequence("a")
+    assert not core.has_unfinished_sequences()
+    assert len(core.scheduler.kv_manager.kv_cache_allocator.free_slots) == 500
