@@ -151,6 +151,30 @@ def cmd_prefill(args):
                       "frac_of_2.5PF": round(flop / t / 2.5e15, 4)}))
 
 
+def cmd_qknorm(args):
+    """Fused q/k norm + rotary + scatter on the bench workload's prefill (142 827 tokens, 16 q / 8 kv heads)."""
+    from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+    prompts, _ = bench.workload(args.num_seqs)
+    t = sum(len(p) for p in prompts)
+    qkv = torch.randn(t, (HQ + 2 * HKV) * 128, device=DEV, dtype=torch.bfloat16)
+    pos = torch.cat([torch.arange(len(p)) for p in prompts]).to(DEV)
+    slots = torch.randperm(t + 1024, device=DEV)[:t]
+    kc = torch.zeros(2, t + 1024, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    table = build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    w = torch.ones(128, device=DEV, dtype=torch.bfloat16)
+    q_out = torch.empty(t, HQ * 128, device=DEV, dtype=torch.bfloat16)
+    i = [0]
+
+    def run():
+        ops.qknorm_rope_store(qkv, pos, table, w, w, 1e-6, slots, kc[i[0]], vc[i[0]], HQ, HKV, q_out=q_out)
+        i[0] ^= 1
+
+    tm = timed(run, 8)
+    nbytes = t * (HQ + 2 * HKV) * 128 * 2 * 2
+    print(json.dumps({"kernel": "qknorm_rope_store", "tokens": t, "us": round(tm * 1e6, 1), "GBps": round(nbytes / tm / 1e9)}))
+
+
 def cmd_sampler(args):
     v = 151936
     for b in (1, 29, 123, 256):
@@ -210,7 +234,7 @@ def cmd_linear(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear"])
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm"])
     ap.add_argument("--every", type=int, default=8)
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
@@ -219,4 +243,4 @@ if __name__ == "__main__":
     ap.add_argument("--uniform-len", type=int, default=0)
     ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
-    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "linear": cmd_linear}[a.cmd](a)
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear}[a.cmd](a)
