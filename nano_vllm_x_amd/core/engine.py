@@ -83,11 +83,12 @@ class Engine(EngineCore):
                  max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False):
         from .model_runner import ModelRunner
 
-        if pp_size != 1:
-            raise NotImplementedError("pipeline parallelism is outside the hot path built here (tp only)")
+        # pp_size > 1: every rank runs this same engine and scheduler; a step passes through the stages in
+        # turn and the sampled ids come back to all of them, so one batch is in flight at a time (the
+        # reference keeps up to pp_size, engine.py:102-117)
         self.model_runner = ModelRunner(model=model, max_bs=max_bs, tp_size=tp_size, nccl_port=nccl_port,
                                         device_ids=device_ids, enforce_eager=enforce_eager, context_len=context_len,
-                                        seed=seed)
+                                        seed=seed, pp_size=pp_size)
         self.model_runner.load_model()
         if kv_cache_size is None:
             kv_cache_size = self.model_runner.profile_kv_cache_size(gpu_memory_utilization)

@@ -42,14 +42,16 @@ def get_model_config_per_gpu(cfg: Qwen3Config, tp_size: int):
 class ModelRunner:
     def __init__(self, model: str, max_bs: int, tp_size: int = 1, nccl_port: int = 29500,
                  device_ids: Optional[list] = None, enforce_eager: bool = False, context_len: int = 2048,
-                 seed: int = 0, config: Optional[Qwen3Config] = None):
+                 seed: int = 0, config: Optional[Qwen3Config] = None, pp_size: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("ModelRunner needs an MI355X: the HIP path has no CPU fallback")
         self.model_path, self.max_bs, self.context_len = model, max_bs, context_len
-        self.enforce_eager, self.seed = enforce_eager, seed
-        self.rank = tpd.init_tensor_parallel(tp_size, port=nccl_port, device_ids=device_ids)
-        self.tp_size = tp_size
-        if tp_size == 1:
+        # a pipeline stage waits for its neighbour inside a step, which a captured graph cannot do: stages
+        # launch their kernels one by one
+        self.enforce_eager, self.seed = enforce_eager or pp_size > 1, seed
+        self.rank = tpd.init_tensor_parallel(tp_size, port=nccl_port, device_ids=device_ids, pp_size=pp_size)
+        self.tp_size, self.pp_size = tp_size, pp_size
+        if tp_size * pp_size == 1:
             torch.cuda.set_device(device_ids[0] if device_ids else 0)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._config_override = config
@@ -66,7 +68,6 @@ class ModelRunner:
         if self.dtype != torch.bfloat16:
             raise NotImplementedError("the HIP kernels are built for bfloat16 checkpoints")
         self.num_heads, self.num_kv_heads, self.head_dim = get_model_config_per_gpu(cfg, self.tp_size)
-        self.num_layers = cfg.num_hidden_layers
         prev = torch.get_default_dtype()
         torch.set_default_dtype(self.dtype)
         try:
@@ -76,6 +77,8 @@ class ModelRunner:
             torch.set_default_dtype(prev)
         self.model.finalize()
         self.model.eval()
+        self.start_layer, self.end_layer = self.model.model.start_layer, self.model.model.end_layer
+        self.num_layers = self.end_layer - self.start_layer     # of this pipeline stage
         if state_dict_iter is not None:
             self.model.load_weights(state_dict_iter)
         else:
@@ -98,7 +101,7 @@ class ModelRunner:
         self.kv_cache_size = kv_cache_size
         self.kv_cache = KVCachePool(dtype=self.dtype, device=self.device, num_tokens=kv_cache_size,
                                     num_layers=self.num_layers, num_heads=self.num_kv_heads, head_dim=self.head_dim,
-                                    start_layer=0, end_layer=self.num_layers)
+                                    start_layer=self.start_layer, end_layer=self.end_layer)
         self.attn_backend = AttentionBackend(kv_cache=self.kv_cache, num_qo_heads=self.num_heads,
                                              num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, dtype=self.dtype,
                                              device=self.device)
@@ -157,7 +160,8 @@ class ModelRunner:
     # -- execution -----------------------------------------------------------------------------------
     @torch.inference_mode()
     def compute_logits(self, batch: ForwardBatch) -> torch.Tensor:
-        """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token."""
+        """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token
+        (None on a pipeline stage other than the last: its output went to the next stage)."""
         decode = batch.forward_mode == ForwardMode.DECODE
         if decode and self.graph is not None and self.graph.is_captured and batch.num_seqs <= self.graph.max_bs \
                 and self.block_table.fits(batch.seqs):
@@ -168,6 +172,8 @@ class ModelRunner:
             if decode:
                 self.stats["eager_decode_steps"] += 1
         self.stats["decode_steps" if decode else "prefill_steps"] += 1
+        if hidden is None:
+            return None
         hidden = self.prepare_last_hidden_states(batch, hidden)
         return self.model.compute_logits(hidden)
 
@@ -186,8 +192,11 @@ class ModelRunner:
         logits = self.compute_logits(batch)
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
-        ids = self.sampler(logits, temperatures, min_ps, top_ps, top_ks, out=self._sample_out[:n] if n <= self.max_bs else None)
-        tpd.tp_broadcast(ids, src=0)
+        if logits is None:      # not the last pipeline stage: the ids arrive with the broadcast
+            ids = self._sample_out[:n] if n <= self.max_bs else torch.empty(n, dtype=torch.int64, device=self.device)
+        else:
+            ids = self.sampler(logits, temperatures, min_ps, top_ps, top_ks, out=self._sample_out[:n] if n <= self.max_bs else None)
+        tpd.broadcast_sampled_ids(ids)
         if n <= self.max_bs:
             self._sample_host[:n].copy_(ids, non_blocking=True)
             ids = None
@@ -211,7 +220,7 @@ class ModelRunner:
         input_ids, positions = self.prepare_input(batch)
         md = self.attn_backend.build_metadata(batch)
         with attention_kv_cache(self.model, md):
-            hidden = self.model(input_ids, positions)
+            hidden = self.model(input_ids, positions) if self.pp_size == 1 else self._run_stage(input_ids, positions)
         # keep the device block table in step with what the scheduler decided
         t = self.attn_backend.last_table
         if batch.forward_mode == ForwardMode.PREFILL:
@@ -222,6 +231,20 @@ class ModelRunner:
             for s in batch.seqs:   # a decode step that ran eagerly: its row (if any) is now stale
                 self.block_table.release(s.seq_id)
         return hidden
+
+    def _run_stage(self, input_ids: torch.Tensor, positions: torch.Tensor) -> Optional[torch.Tensor]:
+        """This pipeline stage's share of a forward pass (worker.py:84-104): take (hidden, residual) from
+        the previous stage, run the local layers, hand the pair on -- one message per direction, the two
+        tensors stacked.  Returns the normed hidden states on the last stage, None elsewhere."""
+        hidden = residual = None
+        if not tpd.pp_is_first():
+            pair = tpd.pp_recv_prev((2, input_ids.shape[0], self.hf_config.hidden_size), self.dtype, self.device)
+            hidden, residual = pair[0], pair[1]
+        hidden, residual = self.model.model.forward_stage(input_ids, positions, hidden, residual, self.model.fused)
+        if tpd.pp_is_last():
+            return hidden
+        tpd.pp_send_next(torch.stack((hidden, residual)))
+        return None
 
     def _execute_model_graph(self, batch: ForwardBatch) -> torch.Tensor:
         bs = batch.num_seqs

@@ -1,9 +1,16 @@
-"""Tensor-parallel process group: one process per GPU, RCCL over xGMI (gloo on CPU for tests).
+"""Process groups: one process per GPU, RCCL over xGMI (gloo on CPU for tests).
 
 Covers what the hot path uses of nanovllmx/distributed/{parallel_state,communication_op}.py: the TP
 group, the in-place all-reduce behind row-parallel linears and the vocab-parallel embedding
 (communication_op.py:41-52,153-156), the last-dim all-gather behind the LM head (:9-39,158-162) and a
 broadcast of sampled ids.  The path shards by KV head, so attention itself needs no exchange.
+
+Pipeline stages (opt-in, pp_size > 1): world = tp_size * pp_size, rank = pp_rank * tp_size + tp_rank
+(worker.py:40-41), a TP group per stage, and point-to-point transfers of the activations between the
+ranks of neighbouring stages that hold the same TP rank: each sends 1/tp of the tensor and the
+receiving stage rebuilds it with an all-gather (communication_op.py:236-346), so an xGMI link carries
+every byte once.  Shapes are known on both sides (every rank runs the same scheduler), so no metadata
+message precedes the payload.
 """
 from __future__ import annotations
 
@@ -16,15 +23,18 @@ import torch.distributed as dist
 _TP_GROUP = None
 _TP_RANK = 0
 _TP_SIZE = 1
+_PP_RANK = 0
+_PP_SIZE = 1
 
 
 def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | None = None, port: int = 29500,
-                         device_ids: list | None = None):
+                         device_ids: list | None = None, pp_size: int = 1):
     """Join (or create) the process group.  Under torchrun the RANK/WORLD_SIZE/MASTER_* variables are
-    used; a single process with tp_size 1 needs no group at all."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE
-    if tp_size <= 1:
-        _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+    used; a single process with tp_size 1 (and one stage) needs no group at all.  Returns the global rank."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE
+    world = tp_size * pp_size
+    if world <= 1:
+        _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = None, 0, 1, 0, 1
         return 0
     if backend is None:
         # NVX_TP_BACKEND=gloo lets several ranks share one GPU (rehearsals on a one-GPU box: RCCL refuses
@@ -43,11 +53,19 @@ def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | N
             dev = device_ids[local] if device_ids else local
             torch.cuda.set_device(dev)
             kw["device_id"] = torch.device("cuda", dev)
-        dist.init_process_group(backend=backend, init_method=init_method, world_size=tp_size, rank=rank,
+        dist.init_process_group(backend=backend, init_method=init_method, world_size=world, rank=rank,
                                 timeout=datetime.timedelta(seconds=120), **kw)
-    assert dist.get_world_size() == tp_size, "world size must equal tp_size (pipeline stages are not built)"
-    _TP_GROUP, _TP_RANK, _TP_SIZE = dist.group.WORLD, dist.get_rank(), tp_size
-    return _TP_RANK
+    assert dist.get_world_size() == world, f"world size {dist.get_world_size()} must equal tp_size * pp_size = {world}"
+    me = dist.get_rank()
+    _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = me % tp_size, tp_size, me // tp_size, pp_size
+    if pp_size == 1:
+        _TP_GROUP = dist.group.WORLD
+    else:   # every rank creates every stage's group, in the same order
+        for stage in range(pp_size):
+            g = dist.new_group(list(range(stage * tp_size, (stage + 1) * tp_size))) if tp_size > 1 else None
+            if stage == _PP_RANK:
+                _TP_GROUP = g
+    return me
 
 
 def tp_rank() -> int:
@@ -58,11 +76,27 @@ def tp_size() -> int:
     return _TP_SIZE
 
 
+def pp_rank() -> int:
+    return _PP_RANK
+
+
+def pp_size() -> int:
+    return _PP_SIZE
+
+
+def pp_is_first() -> bool:
+    return _PP_RANK == 0
+
+
+def pp_is_last() -> bool:
+    return _PP_RANK == _PP_SIZE - 1
+
+
 def _via_host(x: torch.Tensor) -> bool:
     """gloo with device tensors (ranks sharing one GPU in tests and rehearsals): its own device staging
     was seen to hang intermittently with two processes on one GPU, so the tensor is staged through the
     host here, synchronously.  RCCL never takes this path."""
-    return x.is_cuda and dist.get_backend(_TP_GROUP) == "gloo"
+    return x.is_cuda and dist.get_backend() == "gloo"
 
 
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
@@ -93,32 +127,95 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
 
 
 def tp_broadcast(x: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Broadcast within this stage's TP group; `src` is the TP rank of the sender."""
     if _TP_SIZE > 1:
+        g_src = _PP_RANK * _TP_SIZE + src
         if _via_host(x):
             h = x.cpu()
-            dist.broadcast(h, src=src, group=_TP_GROUP)
+            dist.broadcast(h, src=g_src, group=_TP_GROUP)
             x.copy_(h)
         else:
-            dist.broadcast(x, src=src, group=_TP_GROUP)
+            dist.broadcast(x, src=g_src, group=_TP_GROUP)
     return x
 
 
-def tp_all_gather_min_int(value: int, device) -> int:
-    """Smallest `value` over the ranks (KV pool sizing, model_runner.py:166-169)."""
-    if _TP_SIZE == 1:
+def broadcast_sampled_ids(x: torch.Tensor) -> torch.Tensor:
+    """The sampled ids, from TP rank 0 of the last stage to every rank of the job: each rank's scheduler
+    then applies the same tokens and stays in lockstep without host-side messages."""
+    if _TP_SIZE * _PP_SIZE > 1:
+        src = (_PP_SIZE - 1) * _TP_SIZE
+        if _via_host(x):
+            h = x.cpu()
+            dist.broadcast(h, src=src)
+            x.copy_(h)
+        else:
+            dist.broadcast(x, src=src)
+    return x
+
+
+def all_ranks_min_int(value: int, device) -> int:
+    """Smallest `value` over every rank of the job (KV pool sizing, model_runner.py:166-169: all stages
+    and shards must agree on the number of slots because they run the same scheduler)."""
+    if _TP_SIZE * _PP_SIZE == 1:
         return value
-    t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend(_TP_GROUP) == "gloo" else device)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+    t = torch.tensor([value], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
 
 
+tp_all_gather_min_int = all_ranks_min_int
+
+
+# -- pipeline stages: activations between neighbouring stages ---------------------------------------
+def _slice_for_peer(x: torch.Tensor) -> torch.Tensor:
+    """This TP rank's 1/tp of the flattened tensor (communication_op.py:277-279); the whole tensor when
+    its size does not divide."""
+    flat = x.contiguous().view(-1)
+    if _TP_SIZE > 1 and flat.numel() % _TP_SIZE == 0:
+        return flat.view(_TP_SIZE, -1)[_TP_RANK]
+    return flat
+
+
+def pp_send_next(x: torch.Tensor):
+    """Send `x` (identical on the stage's TP ranks) to the next stage."""
+    assert not pp_is_last()
+    part = _slice_for_peer(x)
+    dst = (_PP_RANK + 1) * _TP_SIZE + _TP_RANK
+    dist.send(part.cpu() if _via_host(part) else part, dst=dst)
+
+
+def pp_recv_prev(shape, dtype, device) -> torch.Tensor:
+    """Receive a tensor of a known shape from the previous stage."""
+    assert not pp_is_first()
+    n = 1
+    for d in shape:
+        n *= d
+    sliced = _TP_SIZE > 1 and n % _TP_SIZE == 0
+    src = (_PP_RANK - 1) * _TP_SIZE + _TP_RANK
+    host = torch.device(device).type == "cuda" and dist.get_backend() == "gloo"
+    part = torch.empty(n // _TP_SIZE if sliced else n, dtype=dtype, device="cpu" if host else device)
+    dist.recv(part, src=src)
+    if host:
+        part = part.to(device)
+    if sliced:   # rank-major concatenation restores the flattened tensor
+        full = torch.empty(n, dtype=dtype, device=device)
+        if dist.get_backend() == "gloo" and full.is_cuda:
+            h = torch.empty(n, dtype=dtype)
+            dist.all_gather_into_tensor(h, part.cpu(), group=_TP_GROUP)
+            full.copy_(h)
+        else:
+            dist.all_gather_into_tensor(full, part, group=_TP_GROUP)
+        part = full
+    return part.view(tuple(shape))
+
+
 def barrier():
-    if _TP_SIZE > 1:
-        dist.barrier(group=_TP_GROUP)
+    if _TP_SIZE * _PP_SIZE > 1:
+        dist.barrier()
 
 
 def shutdown():
-    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE
     if dist.is_initialized():
         dist.destroy_process_group()
-    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = None, 0, 1, 0, 1

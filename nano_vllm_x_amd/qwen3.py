@@ -227,15 +227,40 @@ class VocabParallelEmbedding(nn.Module):
         return tpd.tp_all_reduce(out)
 
 
+def stage_layer_range(num_layers: int, pp_rank: int, pp_size: int):
+    """[start, end) of the decoder layers a pipeline stage holds: an even split, the remainder going to
+    the LAST stages one layer each (the first stage also holds the embedding)."""
+    base, extra = divmod(num_layers, pp_size)
+    sizes = [base + (1 if s >= pp_size - extra else 0) for s in range(pp_size)]
+    start = sum(sizes[:pp_rank])
+    return start, start + sizes[pp_rank]
+
+
+class MissingLayer(nn.Module):
+    """Stands where another pipeline stage's module would be, so that layer numbers (and with them
+    checkpoint names and KV-pool layer ids) stay global (qwen3.py:191-206)."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("this module lives on another pipeline stage")
+
+
 class Qwen3Model(nn.Module):
     def __init__(self, cfg: Qwen3Config):
         super().__init__()
         self.config = cfg
-        self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
+        first, last = tpd.pp_is_first(), tpd.pp_is_last()
+        self.start_layer, self.end_layer = stage_layer_range(cfg.num_hidden_layers, tpd.pp_rank(), tpd.pp_size())
+        # tied weights: the last stage needs the embedding matrix for its LM head
+        self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size) \
+            if first or (last and cfg.tie_word_embeddings) else MissingLayer()
         self.register_buffer("rope_table", build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta),
                              persistent=False)
-        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, i, self.rope_table) for i in range(cfg.num_hidden_layers))
-        self.norm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, i, self.rope_table) if self.start_layer <= i < self.end_layer
+                                    else MissingLayer() for i in range(cfg.num_hidden_layers))
+        self.norm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps) if last else MissingLayer()
+
+    def local_layers(self):
+        return self.layers[self.start_layer:self.end_layer]
 
     def forward(self, input_ids, positions, fused: bool = True):
         hidden_states, residual = self.embed_tokens(input_ids), None
@@ -243,6 +268,21 @@ class Qwen3Model(nn.Module):
             hidden_states, residual = layer(positions, hidden_states, residual, fused)
         hidden_states, _ = self.norm(hidden_states, residual)
         return hidden_states
+
+    def forward_stage(self, input_ids, positions, hidden_states, residual, fused: bool = True):
+        """One pipeline stage.  The first stage embeds `input_ids` (hidden_states/residual are None), the
+        others continue from the previous stage's pair; the last returns (normed hidden states, None),
+        the others the pair to hand on (qwen3.py:249-268)."""
+        if tpd.pp_is_first():
+            hidden_states, residual = self.embed_tokens(input_ids), None
+        for layer in self.local_layers():
+            hidden_states, residual = layer(positions, hidden_states, residual, fused)
+        if not tpd.pp_is_last():
+            if hidden_states.dtype == torch.float32:   # K-split partial products of a skinny projection: sum them
+                hidden_states = hidden_states.sum(0).to(residual.dtype)
+            return hidden_states, residual
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states, None
 
 
 class Qwen3ForCausalLM(nn.Module):
@@ -254,19 +294,19 @@ class Qwen3ForCausalLM(nn.Module):
         super().__init__()
         self.config = cfg
         self.model = Qwen3Model(cfg)
-        self.lm_head = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
+        self.lm_head = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size) if tpd.pp_is_last() else MissingLayer()
         self.fused = True
 
     def finalize(self):
         """Call after .to(device, dtype): restore the fp32 rotary table and share it with every layer
         (module-wide casts touch buffers), tie the LM head when the checkpoint says so."""
         m = self.model
-        dev = m.embed_tokens.weight.device
+        dev = next(self.parameters()).device
         m.rope_table = build_cos_sin_cache(self.config.head_dim, self.config.max_position_embeddings,
                                            self.config.rope_theta).to(dev)
-        for layer in m.layers:
+        for layer in m.local_layers():
             layer.self_attn.rope_table = m.rope_table
-        if self.config.tie_word_embeddings:
+        if self.config.tie_word_embeddings and tpd.pp_is_last():
             self.lm_head.weight = m.embed_tokens.weight
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
@@ -283,7 +323,6 @@ class Qwen3ForCausalLM(nn.Module):
         is drawn from the same stream on every rank and then sharded, so TP=N computes the same
         function as TP=1."""
         cfg = self.config
-        dev = self.model.embed_tokens.weight.device
         gen = torch.Generator(device="cpu").manual_seed(seed)
 
         def full(rows, cols, std):
@@ -310,7 +349,6 @@ class Qwen3ForCausalLM(nn.Module):
                 (p + "mlp.down_proj.weight", full(h, cfg.intermediate_size, cfg.intermediate_size ** -0.5)),
                 (p + "input_layernorm.weight", vec(h)), (p + "post_attention_layernorm.weight", vec(h)),
             ])
-        del dev
 
     @torch.no_grad()
     def load_weights(self, weights: Iterable):
@@ -320,13 +358,12 @@ class Qwen3ForCausalLM(nn.Module):
         for name, w in weights:
             for fused_name, ckpt_name, shard_id in self.STACKED:
                 if ckpt_name in name:
-                    target = params[name.replace(ckpt_name, fused_name)]
-                    self._load_stacked(target, w, shard_id, name, tp, rank)
+                    target = params.get(name.replace(ckpt_name, fused_name))
+                    if target is not None:   # else: a layer of another pipeline stage
+                        self._load_stacked(target, w, shard_id, name, tp, rank)
                     break
             else:
-                if name not in params:
-                    if name == "lm_head.weight" and self.config.tie_word_embeddings:
-                        continue
+                if name not in params:   # another stage's tensor, or lm_head of a tied checkpoint
                     continue
                 p = params[name]
                 if name.endswith("embed_tokens.weight") or name == "lm_head.weight":

@@ -1,4 +1,4 @@
-"""Tensor parallelism on the device path: two ranks sharing the one GPU of the test box.
+"""Tensor parallelism and pipeline stages on the device path: two ranks sharing the one GPU of the test box.
 
 RCCL refuses two ranks on one device, so the ranks talk through gloo (device tensors are staged through
 the host) and decode runs eagerly; what is checked is everything tensor parallelism changes on the
@@ -30,16 +30,16 @@ CFG = dict(vocab_size=1000, hidden_size=512, intermediate_size=1536, num_hidden_
 PROMPT_LENS = (5, 19, 33, 8)
 
 
-def _run_model(tp: int, rank: int, port: int):
+def _run_model(tp: int, rank: int, port: int, pp: int = 1):
     from nano_vllm_x_amd import distributed as tpd
     from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, SamplingParams, Sequence
     from nano_vllm_x_amd.core.model_runner import ModelRunner
     from nano_vllm_x_amd.qwen3 import Qwen3Config
 
-    if tp > 1:
-        tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port)
+    if tp * pp > 1:
+        tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port, pp_size=pp)
     r = ModelRunner(model="tp-test", max_bs=8, tp_size=tp, enforce_eager=True, context_len=128,
-                    config=Qwen3Config.from_dict(CFG), seed=5)
+                    config=Qwen3Config.from_dict(CFG), seed=5, pp_size=pp)
     r.load_model()           # seeded random weights: every rank draws the full matrices and keeps its shard
     r.initialize_kv_cache(512)
     rng = np.random.default_rng(9)
@@ -53,32 +53,33 @@ def _run_model(tp: int, rank: int, port: int):
     for step in range(3):
         mode = ForwardMode.PREFILL if step == 0 else ForwardMode.DECODE
         batch = ForwardBatch(forward_mode=mode, num_seqs=len(seqs), seqs=seqs)
-        logits.append(r.compute_logits(batch).float().cpu().numpy())
+        lg = r.compute_logits(batch)
+        logits.append(None if lg is None else lg.float().cpu().numpy())      # None: not the last pipeline stage
         sampled.append(r.execute_model(batch) if step == 2 else None)    # the sampler + broadcast path, once
         for s in seqs:
             s.cached_kv_len = len(s.kv_indices)
             s.token_ids.append(int(rng.integers(0, CFG["vocab_size"])))
             s.kv_indices.append(s.kv_indices[-1] + 1)
-    heads = (r.num_heads, r.num_kv_heads)
+    heads = (r.num_heads, r.num_kv_heads, r.num_layers)
     r.shutdown()
     return logits, sampled[2], heads
 
 
-def _worker(rank, port, q):
+def _worker(rank, port, q, tp, pp):
     try:
-        out = _run_model(2, rank, port)
+        out = _run_model(tp, rank, port, pp)
         q.put((rank, out, None))
     except Exception:   # noqa: BLE001
         q.put((rank, None, traceback.format_exc()))
 
 
-def test_two_ranks_on_one_gpu_match_one_rank():
+def _run_ranks(tp: int, pp: int) -> dict:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, tp, pp)) for r in range(tp * pp)]
     for p in procs:
         p.start()
     results = {}
@@ -88,8 +89,30 @@ def test_two_ranks_on_one_gpu_match_one_rank():
         results[rank] = out
     for p in procs:
         p.join(timeout=60)
+    return results
+
+
+def test_two_pipeline_stages_on_one_gpu_match_one_rank():
+    """pp_size 2: stage 0 holds the embedding and layer 0, stage 1 layer 1, the final norm and the LM head;
+    (hidden, residual) cross between them once per step.  Same arithmetic in the same order as one rank,
+    except that a decode step's K-split partial products are summed and rounded to bf16 before they leave
+    stage 0 (one rank adds them to the residual in fp32), hence the tolerance."""
+    results = _run_ranks(1, 2)
     want, want_ids, heads1 = _run_model(1, 0, 0)
-    assert heads1 == (8, 2) and results[0][2] == (4, 1)
+    assert heads1 == (8, 2, 2) and results[0][2] == (8, 2, 1) and results[1][2] == (8, 2, 1)
+    for step in range(3):
+        assert results[0][0][step] is None
+        a, b = results[1][0][step], want[step]
+        tol = 2.0 ** -6 * np.abs(b).max()
+        assert np.abs(a - b).max() <= tol, (step, np.abs(a - b).max(), tol)
+        assert (a.argmax(-1) == b.argmax(-1)).all()
+    assert results[0][1] == results[1][1] == want_ids      # greedy ids, broadcast from the last stage
+
+
+def test_two_ranks_on_one_gpu_match_one_rank():
+    results = _run_ranks(2, 1)
+    want, want_ids, heads1 = _run_model(1, 0, 0)
+    assert heads1 == (8, 2, 2) and results[0][2] == (4, 1, 2)
     for step in range(3):
         a0, a1, b = results[0][0][step], results[1][0][step], want[step]
         assert np.array_equal(a0, a1), "ranks disagree after the LM-head gather"

@@ -4,6 +4,7 @@ gloo (NVX_TP_BACKEND=gloo), a small Qwen3 geometry, the LLM.generate pump.
 
   NVX_TP_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
       --master-addr 127.0.0.1 --master-port 29513 tools/tp_rehearsal.py
+  NVX_PP=2 ... --nproc-per-node 4 ...     # two stages of two tensor-parallel ranks
 """
 import asyncio, hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +39,8 @@ async def main(llm):
 import faulthandler
 faulthandler.dump_traceback_later(int(os.environ.get("NVX_REHEARSAL_DUMP_S", "60")), exit=True)   # where is a stuck rank?
 log("building")
-llm = LLM(model="rehearsal", max_bs=8, tp_size=world, context_len=128, kv_cache_size=2048, enforce_eager=True)
+pp = int(os.environ.get("NVX_PP", "1"))     # pipeline stages; the remaining factor of the world size is tensor parallel
+llm = LLM(model="rehearsal", max_bs=8, tp_size=world // pp, pp_size=pp, context_len=128, kv_cache_size=2048, enforce_eager=True)
 log("built")
 res = asyncio.run(main(llm))
 digest = hashlib.sha256(repr(res).encode()).hexdigest()[:16]
