@@ -9,6 +9,7 @@ the model and one broadcast of the sampled ids.
 """
 from __future__ import annotations
 
+from collections import deque
 from typing import Optional
 
 from .common import EngineOutput, FinishReason, ForwardBatch, SamplingParams, Sequence
@@ -83,9 +84,10 @@ class Engine(EngineCore):
                  max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False):
         from .model_runner import ModelRunner
 
-        # pp_size > 1: every rank runs this same engine and scheduler; a step passes through the stages in
-        # turn and the sampled ids come back to all of them, so one batch is in flight at a time (the
-        # reference keeps up to pp_size, engine.py:102-117)
+        # pp_size > 1: every rank runs this same engine and scheduler.  Time advances in ticks: at tick t
+        # the scheduler picks batch t (among the sequences not in flight), stage r runs batch t - r, and the
+        # ids of batch t - (pp_size - 1), which the last stage has just finished, reach every rank -- up to
+        # pp_size batches in flight, as engine.py:102-117 keeps them
         self.model_runner = ModelRunner(model=model, max_bs=max_bs, tp_size=tp_size, nccl_port=nccl_port,
                                         device_ids=device_ids, enforce_eager=enforce_eager, context_len=context_len,
                                         seed=seed, pp_size=pp_size)
@@ -99,6 +101,10 @@ class Engine(EngineCore):
                          chunked_prefill=chunked_prefill)
         self.scheduler.on_release = self.model_runner.release_sequence
         self._inflight = None
+        self.pp_size = pp_size
+        self._pp_window: deque = deque(maxlen=max(pp_size, 1))   # the batches of the last pp_size ticks, newest last
+        self._pp_aborts: list = []
+        self.pp_stats = {"ticks": 0, "stage_busy_ticks": 0}
 
     def step(self) -> list:
         if self._inflight is None and not self.begin_step():
@@ -110,10 +116,28 @@ class Engine(EngineCore):
     def begin_step(self) -> bool:
         """Schedule a batch and queue it on the device.  False if there is nothing to run."""
         assert self._inflight is None
+        if self.pp_size > 1:
+            return self._begin_tick()
         batch = self.scheduler.schedule()
         if not batch:
             return False
         self._inflight = self.model_runner.launch_step(batch)
+        return True
+
+    def _begin_tick(self) -> bool:
+        from .. import distributed as tpd
+
+        win = self._pp_window
+        win.append(self.scheduler.schedule() or None)      # a tick without a new batch is a bubble
+        if all(b is None for b in win):
+            win.clear()
+            return False
+        r = tpd.pp_rank()
+        mine = win[-1 - r] if len(win) > r else None
+        out = win[0] if len(win) == self.pp_size else None
+        self.pp_stats["ticks"] += 1
+        self.pp_stats["stage_busy_ticks"] += mine is not None
+        self._inflight = self.model_runner.launch_tick(mine, out)
         return True
 
     def end_step(self) -> list:
@@ -121,17 +145,33 @@ class Engine(EngineCore):
         handle, self._inflight = self._inflight, None
         if handle is None:
             return []
-        return self.update_from_output(handle[0], self.model_runner.finish_step(handle))
+        ids = self.model_runner.finish_step(handle)
+        outs = self.update_from_output(handle[0], ids) if handle[0] is not None else []
+        if self._pp_aborts:
+            waiting, self._pp_aborts = self._pp_aborts, []
+            for seq_id in waiting:
+                self.abort_sequence(seq_id)
+        return outs
+
+    def abort_sequence(self, sequence_id: str):
+        """With batches in flight across stages an abort waits until the sequence's step has come back:
+        a later stage still has to run the batch exactly as the earlier stages saw it."""
+        if self.pp_size > 1 and sequence_id in self.scheduler.scheduled:
+            self._pp_aborts.append(sequence_id)
+            return
+        super().abort_sequence(sequence_id)
 
     @property
     def step_in_flight(self) -> bool:
-        return self._inflight is not None
+        return self._inflight is not None or any(b is not None for b in self._pp_window)
 
     def reset(self):
         """Forget every sequence and every cached prefix (fresh scheduler, same pool and graphs)."""
         if self._inflight is not None:
             self.model_runner.finish_step(self._inflight)
             self._inflight = None
+        while self.pp_size > 1 and self.step_in_flight:   # drain the pipeline: every stage must see every batch
+            self.step()
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
         self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse,

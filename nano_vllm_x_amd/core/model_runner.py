@@ -58,6 +58,7 @@ class ModelRunner:
         self.graph: Optional[HIPGraph] = None
         self.block_table: Optional[BlockTable] = None
         self._sp_key, self._sp_dev = None, None
+        self._stage_output, self._defer_stage_send = None, False
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
 
     # -- set-up -----------------------------------------------------------------------------------
@@ -202,8 +203,42 @@ class ModelRunner:
             ids = None
         return (batch, ids, t0)
 
+    @torch.inference_mode()
+    def launch_tick(self, mine: Optional[ForwardBatch], out: Optional[ForwardBatch]):
+        """One tick of the pipeline with several batches in flight: this stage runs `mine` (the batch
+        that reached it, if any), then every rank takes part in the broadcast of the ids of `out` (the
+        batch the LAST stage ran this tick, if any), and only then is this stage's output sent on -- the
+        next stage posts its receive at the start of its next tick, after the same broadcast, so the
+        order of operations is the same chain on every rank and cannot form a cycle.  On the last
+        stage `mine is out`."""
+        t0 = time.perf_counter()
+        logits = None
+        if mine is not None and mine.num_seqs:
+            self._defer_stage_send = True
+            try:
+                logits = self.compute_logits(mine)
+            finally:
+                self._defer_stage_send = False
+        ids = None
+        if out is not None and out.num_seqs:
+            n = out.num_seqs
+            if tpd.pp_is_last():
+                assert mine is out and logits is not None
+                temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(out)
+                ids = self.sampler(logits, temperatures, min_ps, top_ps, top_ks, out=self._sample_out[:n] if n <= self.max_bs else None)
+            else:
+                ids = self._sample_out[:n] if n <= self.max_bs else torch.empty(n, dtype=torch.int64, device=self.device)
+            tpd.broadcast_sampled_ids(ids)
+            if n <= self.max_bs:
+                self._sample_host[:n].copy_(ids, non_blocking=True)
+                ids = None
+        else:
+            out = None
+        self.send_stage_output()
+        return (out, ids, t0)
+
     def finish_step(self, handle) -> list:
-        if handle is None:
+        if handle is None or handle[0] is None:
             return []
         batch, ids, t0 = handle
         n = batch.num_seqs
@@ -243,8 +278,16 @@ class ModelRunner:
         hidden, residual = self.model.model.forward_stage(input_ids, positions, hidden, residual, self.model.fused)
         if tpd.pp_is_last():
             return hidden
-        tpd.pp_send_next(torch.stack((hidden, residual)))
+        self._stage_output = torch.stack((hidden, residual))
+        if not self._defer_stage_send:
+            self.send_stage_output()
         return None
+
+    def send_stage_output(self):
+        """Hand the pair computed by _run_stage to the next stage (a no-op if there is none waiting)."""
+        out, self._stage_output = self._stage_output, None
+        if out is not None:
+            tpd.pp_send_next(out)
 
     def _execute_model_graph(self, batch: ForwardBatch) -> torch.Tensor:
         bs = batch.num_seqs

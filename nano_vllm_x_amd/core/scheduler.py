@@ -228,9 +228,14 @@ class Scheduler:
                 self.alloc_kv_slots(seq)
                 return True
             except RuntimeError:
-                if not self.running:
+                # the victim is the youngest running sequence that is not in flight (with one batch in flight
+                # none of `running` is here: the picked ones were taken off it; with pipeline stages an
+                # earlier batch's sequences are still being computed and keep their slots)
+                victim = next((s for s in reversed(self.running) if s.seq_id not in self.scheduled), None)
+                if victim is None:
                     return False       # nothing left to preempt: stays at the head of `running`
-                self._preempt_detached(self.running.pop())
+                self.running.remove(victim)
+                self._preempt_detached(victim)
 
     # -- preemption -------------------------------------------------------------------------------
     def _preempt_detached(self, seq: Sequence):

@@ -174,3 +174,71 @@ def _case_stage_weights(rank: int, tp: int, pp: int):
 @pytest.mark.parametrize("tp,pp", [(1, 2), (2, 2)])
 def test_each_stage_keeps_its_slice_of_the_model(tp, pp):
     _run("_case_stage_weights", tp, pp)
+
+
+# -- tick bookkeeping of the engine, with a stand-in for the device side ---------------------------
+class _FakeRunner:
+    """Records which batch each tick gives this stage and which batch's ids come back; the "sampled" id
+    of a sequence is a function of its length, so every stage's replica of the scheduler agrees."""
+
+    def __init__(self):
+        self.ran, self.retired = [], []
+
+    def launch_tick(self, mine, out):
+        self.ran.append(None if mine is None else tuple(s.seq_id for s in mine.seqs))
+        self.retired.append(None if out is None else tuple(s.seq_id for s in out.seqs))
+        return (out, None, 0.0)
+
+    def finish_step(self, handle):
+        return [] if handle[0] is None else [100 + len(s.token_ids) for s in handle[0].seqs]
+
+    def release_sequence(self, seq):
+        pass
+
+
+def _fake_engine(pp_rank: int, pp: int, monkeypatch):
+    from collections import deque
+
+    from nano_vllm_x_amd import distributed as tpd
+    from nano_vllm_x_amd.core.engine import Engine, EngineCore
+
+    monkeypatch.setattr(tpd, "_PP_RANK", pp_rank)
+    monkeypatch.setattr(tpd, "_PP_SIZE", pp)
+    eng = Engine.__new__(Engine)
+    EngineCore.__init__(eng, kv_cache_size=4096, max_bs=2, context_len=256)
+    eng.model_runner = _FakeRunner()
+    eng._inflight, eng.pp_size, eng._pp_window, eng._pp_aborts = None, pp, deque(maxlen=pp), []
+    eng.pp_stats = {"ticks": 0, "stage_busy_ticks": 0}
+    return eng
+
+
+@pytest.mark.parametrize("pp", [2, 3])
+def test_every_stage_runs_every_batch_once_in_schedule_order(pp, monkeypatch):
+    from nano_vllm_x_amd.core.common import SamplingParams
+
+    logs = []
+    for r in range(pp):
+        eng = _fake_engine(r, pp, monkeypatch)
+        for i in range(7):
+            eng.add_sequence(f"s{i}", list(range(3 + i)), SamplingParams(ignore_eos=True, max_new_tokens=2 + i % 3))
+        outs = []
+        for _ in range(200):
+            if not (eng.has_unfinished_sequences() or eng.step_in_flight):
+                break
+            outs.extend((o.seq_id, o.new_token_id, o.is_finished) for o in eng.step())
+            if len(outs) == 3:
+                eng.abort_sequence("s5")        # in flight or not, the stages must still agree
+        assert not eng.has_unfinished_sequences() and not eng.step_in_flight
+        run = eng.model_runner
+        logs.append((outs, run.ran, run.retired))
+        done = [b for b in run.retired if b is not None]
+        assert [b for b in run.ran if b is not None] == done               # each batch once, in retirement (= schedule) order
+        # stage r sees a batch r ticks after it was scheduled, and the ids pp-1 ticks after
+        first = next(i for i, b in enumerate(run.ran) if b is not None)
+        assert first == r and next(i for i, b in enumerate(run.retired) if b is not None) == pp - 1
+        assert sum(b is not None for b in run.ran) >= 0.6 * len(run.ran)     # the stages overlap
+    for r in range(1, pp):
+        assert logs[r][0] == logs[0][0]                       # same tokens, same finish decisions on every stage
+        assert logs[r][2] == logs[0][2]
+        # the stage's own sequence of batches is stage 0's, shifted by r ticks
+        assert [b for b in logs[r][1] if b is not None] == [b for b in logs[0][1] if b is not None]
