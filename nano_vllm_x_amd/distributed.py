@@ -54,7 +54,7 @@ def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | N
             torch.cuda.set_device(dev)
             kw["device_id"] = torch.device("cuda", dev)
         dist.init_process_group(backend=backend, init_method=init_method, world_size=world, rank=rank,
-                                timeout=datetime.timedelta(seconds=120), **kw)
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("NVX_DIST_TIMEOUT_S", "600"))), **kw)
     assert dist.get_world_size() == world, f"world size {dist.get_world_size()} must equal tp_size * pp_size = {world}"
     me = dist.get_rank()
     _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = me % tp_size, tp_size, me // tp_size, pp_size
