@@ -124,11 +124,12 @@ class Engine(EngineCore):
         self._inflight = self.model_runner.launch_step(batch)
         return True
 
-    def _begin_tick(self) -> bool:
+    def _begin_tick(self, admit: bool = True) -> bool:
+        """`admit=False` only moves the batches already in flight on by one stage (draining)."""
         from .. import distributed as tpd
 
         win = self._pp_window
-        win.append(self.scheduler.schedule() or None)      # a tick without a new batch is a bubble
+        win.append((self.scheduler.schedule() or None) if admit else None)      # a tick without a new batch is a bubble
         if all(b is None for b in win):
             win.clear()
             return False
@@ -170,8 +171,8 @@ class Engine(EngineCore):
         if self._inflight is not None:
             self.model_runner.finish_step(self._inflight)
             self._inflight = None
-        while self.pp_size > 1 and self.step_in_flight:   # drain the pipeline: every stage must see every batch
-            self.step()
+        while self.pp_size > 1 and self._begin_tick(admit=False):   # drain: every stage must see every batch in flight
+            self.end_step()
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
         self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse,

@@ -242,3 +242,21 @@ def test_every_stage_runs_every_batch_once_in_schedule_order(pp, monkeypatch):
         assert logs[r][2] == logs[0][2]
         # the stage's own sequence of batches is stage 0's, shifted by r ticks
         assert [b for b in logs[r][1] if b is not None] == [b for b in logs[0][1] if b is not None]
+
+
+def test_draining_moves_batches_in_flight_through_every_stage_without_admitting(monkeypatch):
+    from nano_vllm_x_amd.core.common import SamplingParams
+
+    for r in range(3):
+        eng = _fake_engine(r, 3, monkeypatch)
+        for i in range(6):
+            eng.add_sequence(f"s{i}", list(range(4 + i)), SamplingParams(ignore_eos=True, max_new_tokens=50))
+        for _ in range(5):
+            eng.step()
+        run = eng.model_runner
+        scheduled_so_far = 5                                    # one batch per tick: max_bs 2, six sequences
+        while eng._begin_tick(admit=False):
+            eng.end_step()
+        assert not eng.step_in_flight
+        assert sum(b is not None for b in run.ran) == scheduled_so_far      # nothing new was admitted ...
+        assert [b for b in run.ran if b is not None] == [b for b in run.retired if b is not None]   # ... and nothing was left behind
