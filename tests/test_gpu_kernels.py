@@ -199,7 +199,7 @@ def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
     return ws
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2), (8, 4), (4, 2), (2, 1)])
 def test_decode_attention_small(ops, hq, hkv):
     _decode_case(ops, 10 + hq, [1, 2, 31, 32, 33, 127, 128, 129, 300], hq, hkv)
 
@@ -269,7 +269,7 @@ def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
     assert not (d > tol).any(), f"prefill vs per-row decode: max diff {d.max():.3e}"
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2), (8, 4), (4, 2), (2, 1)])
 def test_prefill_attention_small(ops, hq, hkv):
     q_lens = [1, 5, 31, 32, 33, 64, 65, 130, 200]
     _prefill_case(ops, 30 + hq, q_lens, q_lens, hq, hkv)
@@ -453,7 +453,7 @@ def test_sampler_sliced_rows_draw_the_same_tokens(ops):
 
 # -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m", [1, 5, 16, 29, 64, 123, 256])
-@pytest.mark.parametrize("n,k", [(4096, 1024), (1024, 2048), (1024, 3072), (48, 512)])
+@pytest.mark.parametrize("n,k", [(4096, 1024), (1024, 2048), (1024, 3072), (48, 512), (2048, 1024), (512, 1024), (1024, 1536)])
 def test_linear_decode_matches_fp32_matmul(ops, m, n, k):
     """fp32-accumulated MFMA product against torch fp32 matmul of the same bf16 operands: the only
     difference is summation order, so |err| <= 2^-8 |ref| (output rounding) + 1e-3."""

@@ -200,14 +200,35 @@ def test_decode_projections_fused_path_matches_library_gemm_path():
     library GEMM (module flag fused=False runs the op-by-op graph).  Same bf16 operands, fp32
     accumulation in both, different summation order: logits agree to 2^-6 * max|logit|."""
     from nano_vllm_x_amd import qwen3
-    from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, Sequence
-    from nano_vllm_x_amd.core.model_runner import ModelRunner
 
     cfg = qwen3.Qwen3Config(vocab_size=1024, hidden_size=512, intermediate_size=1536, num_hidden_layers=3,
                             num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=256,
                             tie_word_embeddings=False)
+    calls = _fused_vs_library(cfg)
+    assert calls == 3 * 3 * 4, calls        # 3 decode steps x 3 layers x (qkv, o, gate_up, down)
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_shapes_of_one_tensor_parallel_rank_of_qwen3_0_6b(tp):
+    """The kernels see per-rank shapes under tensor parallelism: Qwen3-0.6B over 2, 4 or 8 ranks leaves a
+    rank 8/4, 4/2 or 2/1 query/KV heads and 1536, 768 or 384 MLP columns at hidden size 1024.  A one-rank
+    model of exactly that geometry (two layers, small vocabulary) runs the HIP path against the
+    library-GEMM op-by-op path; what the ranks exchange is covered by the two-rank tests."""
+    from nano_vllm_x_amd import qwen3
+
+    cfg = qwen3.Qwen3Config(vocab_size=2048, hidden_size=1024, intermediate_size=3072 // tp, num_hidden_layers=2,
+                            num_attention_heads=16 // tp, num_key_value_heads=8 // tp, head_dim=128,
+                            max_position_embeddings=256, tie_word_embeddings=False)
+    assert _fused_vs_library(cfg) > 0
+
+
+def _fused_vs_library(cfg) -> int:
+    from nano_vllm_x_amd import qwen3
+    from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, Sequence
+    from nano_vllm_x_amd.core.model_runner import ModelRunner
+
     rng = np.random.default_rng(4)
-    prompts = [rng.integers(0, 1024, size=int(n)).tolist() for n in (5, 17, 33, 9, 21)]
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(n)).tolist() for n in (5, 17, 33, 9, 21)]
     outs = {}
     calls = {"n": 0}
     real = qwen3.ops.linear_decode
@@ -236,19 +257,19 @@ def test_decode_projections_fused_path_matches_library_gemm_path():
                 got.append(logits)
                 for i, s in enumerate(seqs):
                     s.cached_kv_len = len(s.kv_indices)
-                    s.token_ids.append(int(rng.integers(0, 1024)) if fused else outs["fed"][step][i])
+                    s.token_ids.append(int(rng.integers(0, cfg.vocab_size)) if fused else outs["fed"][step][i])
                     s.kv_indices.append(s.kv_indices[-1] + 1)
                 if fused:
                     outs.setdefault("fed", []).append([s.token_ids[-1] for s in seqs])
         finally:
             qwen3.ops.linear_decode = real
         outs[fused] = got
-    assert calls["n"] == 3 * 3 * 4, calls        # 3 decode steps x 3 layers x (qkv, o, gate_up, down)
     for step in range(4):
         a, b = outs[True][step], outs[False][step]
         tol = 2.0 ** -6 * np.abs(b).max()
         assert np.abs(a - b).max() <= tol, (step, np.abs(a - b).max(), tol)
         assert (a.argmax(-1) == b.argmax(-1)).mean() >= 0.8
+    return calls["n"]
 
 
 def test_small_pool_forces_preemption_and_eviction_under_graph_decode():
