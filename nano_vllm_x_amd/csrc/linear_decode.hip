@@ -38,11 +38,15 @@ __device__ __forceinline__ int lin_slot(int j, int q, int r) { return j * 64 + q
 // STAGED = true: each wave loads its rows coalesced (32 lanes x 16 B = 512 contiguous bytes per row),
 //   parks them in a private 8 KB LDS area (pieces XOR-swizzled by row) and reads the fragments from
 //   there: one more LDS hop per 256 k, a quarter of the address-unit work.  Used above 48 rows.
-template <int MODE, int KC, bool STAGED>
+// WIDE (modes 0 and 2): the workgroup owns 32 rows of W instead of 16, so half as many workgroups re-read
+// the activations from L2.  gridDim.z > 1 deals the 16-row tiles of X round-robin to that many workgroups
+// per W slice (their ids differ by a multiple of 8, so they share an XCD and its L2 copy of the slice).
+template <int MODE, int KC, bool STAGED, bool WIDE = false>
 __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* __restrict__ w, void* __restrict__ y, int m_rows, int n_rows,
     int k_total) {
-    constexpr int HALVES = MODE == 1 ? 2 : 1;
+    static_assert(!(WIDE && MODE == 1), "the gate/up mode already owns 32 rows of W");
+    constexpr int HALVES = (MODE == 1 || WIDE) ? 2 : 1;
     constexpr int STEPS = KC / 32;               // MFMA k-steps per tile
     constexpr int GPT = STAGED ? STEPS / 8 : ((MODE == 1 && KC == 1024) ? 4 : 2);   // groups per tile
     constexpr int GROUP = STEPS / GPT;           // k-steps per group (direct: half a tile in flight; staged: 8 = 256 k)
@@ -56,16 +60,18 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad = lane >> 4, l16 = lane & 15;
     const int n_out = MODE == 1 ? n_rows / 2 : n_rows;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (WIDE ? 32 : 16);
     const int k0 = blockIdx.y * KC;
+    const int half_stride = MODE == 1 ? n_out : 16;   // W row distance between the two halves
+    const int msplit = gridDim.z, mz = blockIdx.z;
 
     // ---- this wave's work: (tile, group of 8 k-steps) items; the first item's X loads go in flight before W
-    const int tiles = (m_rows + 15) / 16;
+    const int tiles = ((m_rows + 15) / 16 - mz + msplit - 1) / msplit;   // of this workgroup: mz, mz + msplit, ...
     const int my_tiles = tiles > wave ? (tiles - wave + LIN_WAVES - 1) / LIN_WAVES : 0;
     const int n_items = my_tiles * GPT;
     nvx_u32x4 b_even[GROUP], b_odd[STAGED ? 1 : GROUP];
     auto load_b = [&](nvx_u32x4 (&dst)[GROUP], int item) {
-        const int tile = wave + LIN_WAVES * (item / GPT), group = item % GPT;
+        const int tile = (wave + LIN_WAVES * (item / GPT)) * msplit + mz, group = item % GPT;
         if constexpr (STAGED) {
             // load u: rows 2u and 2u+1 of the tile, 32 lanes x 16 B = the 256 k of this group, contiguous
 #pragma unroll
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
             const int p = u * LIN_THREADS + tid;
             const int h = p / PIECES_HALF, ph = p % PIECES_HALF;
             const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
-            v[u] = *reinterpret_cast<const nvx_u32x4*>(w + (int64_t)(n0 + h * n_out + r) * k_total + k0 + kp * 8);
+            v[u] = *reinterpret_cast<const nvx_u32x4*>(w + (int64_t)(n0 + h * half_stride + r) * k_total + k0 + kp * 8);
         }
 #pragma unroll
         for (int u = 0; u < WLOADS; ++u) {
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     nvx_f32x4 acc[HALVES];
     nvx_u32x4* my_stage = stage + (STAGED ? wave * (16 * 32) : 0);
     auto compute = [&](const nvx_u32x4 (&bfrag)[GROUP], int item) {
-        const int tile = wave + LIN_WAVES * (item / GPT), g = item % GPT;
+        const int tile = (wave + LIN_WAVES * (item / GPT)) * msplit + mz, g = item % GPT;
         if (g == 0) {
 #pragma unroll
             for (int h = 0; h < HALVES; ++h) acc[h] = nvx_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,8 +141,11 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
         if (row >= m_rows) return;
         const int col = n0 + quad * 4;
         if (MODE == 0) {
-            uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_rows + col;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[0][2], acc[0][3]));
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_rows + col + h * 16;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[h][0], acc[h][1]), pack_bf16x2(acc[h][2], acc[h][3]));
+            }
         } else if (MODE == 1) {
             float o[4];
 #pragma unroll
@@ -148,8 +157,11 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
             uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_out + col;
             *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         } else {
-            float* dst = reinterpret_cast<float*>(y) + ((int64_t)blockIdx.y * m_rows + row) * n_rows + col;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                float* dst = reinterpret_cast<float*>(y) + ((int64_t)blockIdx.y * m_rows + row) * n_rows + col + h * 16;
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+            }
         }
     };
     if constexpr (STAGED) {
@@ -184,6 +196,17 @@ static int lin_staged_min_rows() {
     return v;
 }
 
+static int lin_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// Tuning knobs.  NVX_LIN_WIDE_MIN = rows from which modes 0/2 use 32-row workgroups (0 = never; default:
+// whenever the activations are staged), NVX_LIN_MSPLIT = workgroups per W slice in that case.  Measured on
+// MI355X with the Qwen3-0.6B projections (tools/kernel_bench.py linear, us, 16-row -> 32-row x 2):
+// 176 rows: qkv 9.4 -> 7.8, o 6.1 -> 5.2, down 7.7 -> 6.6; 64 rows: 6.1 -> 6.0, 4.2 -> 4.0, 5.1 -> 5.0.
+// 32-row workgroups alone are slower (half the workgroups, each with twice the serial work), and dealing
+// the X tiles of a 16-row slice to two workgroups is slower still (W is then fetched twice, X as often as
+// before): the pair halves the X traffic at the same W traffic and the same number of workgroups.
+static int lin_wide_min_rows() { static int v = -1; if (v < 0) v = lin_env_int("NVX_LIN_WIDE_MIN", 1); return v; }
+static int lin_msplit() { static int v = -1; if (v < 0) { v = lin_env_int("NVX_LIN_MSPLIT", 2); if (v < 1 || v > 8) v = 2; } return v; }
+
 static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
 
 extern "C" int nvx_linear_decode_splits(int64_t n, int64_t k) {
@@ -211,13 +234,16 @@ extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void
     NVX_REQUIRE(nvx_aligned16(x) && nvx_aligned16(w) && nvx_aligned16(y), NVX_EINVAL, "nvx_linear_decode: pointers must be 16-byte aligned");
     const int kc = (int)(k / k_splits);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(n_out / 16), (unsigned)k_splits);
     const bool staged = m > lin_staged_min_rows();
-#define NVX_LIN(MODE, KC, ST) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC, ST>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
-                                                 x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
-#define NVX_LIN_KC(MODE, ST) do { if (kc == 512) NVX_LIN(MODE, 512, ST); else if (kc == 768) NVX_LIN(MODE, 768, ST); else NVX_LIN(MODE, 1024, ST); } while (0)
-#define NVX_LIN_ST(MODE) do { if (staged) NVX_LIN_KC(MODE, true); else NVX_LIN_KC(MODE, false); } while (0)
-    if (mode == 0) NVX_LIN_ST(0); else if (mode == 1) NVX_LIN_ST(1); else NVX_LIN_ST(2);
+    const bool wide = mode != 1 && staged && lin_wide_min_rows() > 0 && m >= lin_wide_min_rows() && n_out % 32 == 0;
+    const int msplit = wide && ((n_out / 32) * k_splits) % 8 == 0 ? lin_msplit() : 1;
+    const dim3 grid((unsigned)(n_out / (wide ? 32 : 16)), (unsigned)k_splits, (unsigned)msplit);
+#define NVX_LIN(MODE, KC, ST, WD) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC, ST, WD>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
+                                                     x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
+#define NVX_LIN_KC(MODE, ST, WD) do { if (kc == 512) NVX_LIN(MODE, 512, ST, WD); else if (kc == 768) NVX_LIN(MODE, 768, ST, WD); else NVX_LIN(MODE, 1024, ST, WD); } while (0)
+#define NVX_LIN_ST(MODE) do { if (staged) NVX_LIN_KC(MODE, true, false); else NVX_LIN_KC(MODE, false, false); } while (0)
+    if (wide) { if (mode == 0) NVX_LIN_KC(0, true, true); else NVX_LIN_KC(2, true, true); }
+    else if (mode == 0) NVX_LIN_ST(0); else if (mode == 1) NVX_LIN_ST(1); else NVX_LIN_ST(2);
 #undef NVX_LIN_ST
 #undef NVX_LIN_KC
 #undef NVX_LIN

@@ -81,7 +81,7 @@ def load_config(model: str) -> Qwen3Config:
 # Largest decode batch for which the skinny projection kernel (ops.linear_decode) beats the library
 # GEMM, per projection; measured on MI355X with the Qwen3-0.6B shapes (tools/kernel_bench.py linear).
 # Above these, and for every prefill, the projection is a library GEMM.
-DECODE_LINEAR_MAX_ROWS = {"qkv": 176, "o": 256, "gate_up": 256, "down": 256}
+DECODE_LINEAR_MAX_ROWS = {"qkv": 256, "o": 256, "gate_up": 256, "down": 256}
 # ... and largest weight matrix.  The skinny kernel wins where a projection is latency-bound (a few MB of
 # weights: one slice per workgroup, fetched in one go); a matrix of tens of MB is a bandwidth-bound stream,
 # which the library GEMM sustains better (Qwen3-8B o_proj, 33 MB: 28 us here vs ~12 us of streaming).
