@@ -54,6 +54,10 @@ class Sequence:
     kv_indices: list = field(default_factory=list)   # slot of token i, for every token that has a KV row
     cached_kv_len: int = 0                           # tokens whose KV rows are already written
 
+    # plain class attributes (not dataclass fields), set per object where they apply
+    partial_of = None      # chunked prefill: the sequence this truncated copy stands for
+    length_limit = None    # engine cache: total length at which a LENGTH stop rule fires (0 = none)
+
     @property
     def num_new_tokens(self) -> int:
         """Tokens the next forward pass must process."""

@@ -12,7 +12,7 @@ from __future__ import annotations
 from collections import deque
 from typing import Optional
 
-from .common import EngineOutput, FinishReason, ForwardBatch, SamplingParams, Sequence
+from .common import EngineOutput, FinishReason, ForwardBatch, SamplingParams, Sequence, SequenceStatus
 from .scheduler import Scheduler
 
 
@@ -59,21 +59,59 @@ class EngineCore:
             return True, FinishReason.LENGTH
         return False, None
 
-    def update_from_output(self, batch: ForwardBatch, output_ids: list) -> list:
+    def _length_limit(self, seq: Sequence) -> int:
+        """Smallest total length at which one of the LENGTH rules of _is_sequence_finished fires (0 = none).
+        A sequence's sampling parameters never change, so this is computed once per sequence."""
+        sp = seq.sampling_params
+        limits = []
+        if sp.max_tokens:
+            limits.append(sp.max_tokens)
+        if sp.max_new_tokens:
+            limits.append(seq.prompt_len + sp.max_new_tokens)
+        if self.stop_at_context_len:
+            limits.append(self.context_len)
+        return min(limits) if limits else 0
+
+    def fold_output(self, batch: ForwardBatch, output_ids: list) -> list:
+        """Apply one step's sampled ids to the sequences (Scheduler.update_sequence, the stop rules of
+        _is_sequence_finished and Scheduler.finish_sequence, engine.py:119-141) and return one
+        (seq_id, token, finished, reason, prompt tokens, generated tokens) tuple per sequence.  This is
+        the host work that stands between two device steps, so the per-sequence part is written out
+        in line: same decisions in the same order as the three calls it replaces."""
         outs = []
         sched = self.scheduler
-        update, finished, finish = sched.update_sequence, self._is_sequence_finished, sched.finish_sequence
+        scheduled, prefilling, finish = sched.scheduled, sched.prefilling, sched.finish_sequence
+        running = SequenceStatus.RUNNING
         for seq, tok in zip(batch.seqs, output_ids):
-            if getattr(seq, "partial_of", None) is not None:   # a chunk that stops before the prompt does: no token yet
+            if seq.partial_of is not None:   # a chunk that stops before the prompt does: no token yet
                 sched.finish_chunk(seq)
                 continue
-            update(seq, tok)
-            done, why = finished(seq)
-            if done:
-                finish(seq)
-            outs.append(EngineOutput(seq.seq_id, tok, done, why, seq.prompt_len, seq.num_tokens - seq.prompt_len))
+            toks = seq.token_ids
+            if seq.status is running:
+                scheduled.remove(seq.seq_id)
+                if prefilling:
+                    prefilling.pop(seq.seq_id, None)   # its last chunk has run
+                seq.cached_kv_len = len(seq.kv_indices)
+                toks.append(tok)
+                seq.num_tokens = len(toks)
+            n = seq.num_tokens
+            limit = seq.length_limit
+            if limit is None:
+                limit = seq.length_limit = self._length_limit(seq)
+            sp = seq.sampling_params
+            if not sp.ignore_eos and toks[-1] == sp.eos_token_id:
+                why = FinishReason.STOP
+            elif limit and n >= limit:
+                why = FinishReason.LENGTH
+            else:
+                outs.append((seq.seq_id, tok, False, None, seq.prompt_len, n - seq.prompt_len))
+                continue
+            finish(seq)
+            outs.append((seq.seq_id, tok, True, why, seq.prompt_len, n - seq.prompt_len))
         return outs
 
+    def update_from_output(self, batch: ForwardBatch, output_ids: list) -> list:
+        return [EngineOutput(*t) for t in self.fold_output(batch, output_ids)]
 
 class Engine(EngineCore):
     """Engine with the reference's nine constructor arguments (engine.py:13-24, llm.py:17-28)."""
@@ -143,16 +181,30 @@ class Engine(EngineCore):
 
     def end_step(self) -> list:
         """Wait for the step in flight and fold its tokens into the sequences."""
+        return [EngineOutput(*t) for t in self._finish_inflight()]
+
+    def step_overlapped(self) -> list:
+        """step() for a driver that keeps the device busy: wait for the step in flight (or run one), fold
+        its tokens in, queue the NEXT step, and only then build the output objects -- whatever the host
+        does between the arrival of one step's ids and the launch of the next is time the device idles."""
+        if self._inflight is None and not self.begin_step():
+            return []
+        raw = self._finish_inflight()
+        if self.has_unfinished_sequences():
+            self.begin_step()
+        return [EngineOutput(*t) for t in raw]
+
+    def _finish_inflight(self) -> list:
         handle, self._inflight = self._inflight, None
         if handle is None:
             return []
         ids = self.model_runner.finish_step(handle)
-        outs = self.update_from_output(handle[0], ids) if handle[0] is not None else []
+        raw = self.fold_output(handle[0], ids) if handle[0] is not None else []
         if self._pp_aborts:
             waiting, self._pp_aborts = self._pp_aborts, []
             for seq_id in waiting:
                 self.abort_sequence(seq_id)
-        return outs
+        return raw
 
     def abort_sequence(self, sequence_id: str):
         """With batches in flight across stages an abort waits until the sequence's step has come back:

@@ -162,10 +162,13 @@ class RadixTree:
                 break
             child.access_time = self._clock.tick()
             edge = child.key
-            m = 0
             lim = min(len(edge), n_key - pos)
-            while m < lim and edge[m] == key[pos + m]:
-                m += 1
+            if edge[:lim] == tuple(key[pos:pos + lim]):   # whole-edge comparison at C speed (the common case)
+                m = lim
+            else:
+                m = 0
+                while edge[m] == key[pos + m]:      # a mismatch exists below lim
+                    m += 1
             pos += m
             if m < len(edge):
                 node = self._split_node(child, m)

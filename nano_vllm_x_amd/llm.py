@@ -74,11 +74,10 @@ class LLM:
         eng = self.engine
         try:
             while eng.has_unfinished_sequences() or eng.step_in_flight:
-                outs = eng.step()          # waits for the step in flight (or runs one)
-                # the next step goes to the device before this one's tokens are handed out: queue wake-ups,
-                # detokenisation and the consumers' own code then run while the device is busy
-                if eng.has_unfinished_sequences():
-                    eng.begin_step()
+                # waits for the step in flight (or runs one) and queues the next step before this one's tokens
+                # are handed out: queue wake-ups, detokenisation and the consumers' own code then run while
+                # the device is busy
+                outs = eng.step_overlapped()
                 for out in outs:
                     q = self.request_states.get(out.seq_id)
                     if q is None:
