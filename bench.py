@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--run-ahead", type=int, default=1,
+                    help="1: queue decode step N+1 before step N's ids reach the host (same batches, same tokens; one rank only)")
     ap.add_argument("--cpu-requests", type=int, default=8)
     ap.add_argument("--cpu-new-tokens", type=int, default=48)
     ap.add_argument("--roofline-every", type=int, default=8)
@@ -224,7 +226,8 @@ def main():
         # 114 688 B per token) instead of letting it grow with the number of ranks
         kv_size = 2_000_000
     llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
-              context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size)
+              context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size,
+              run_ahead=bool(args.run_ahead) and world == 1)
     init_s = time.perf_counter() - t_init
     eng = llm.engine
 
@@ -255,7 +258,8 @@ def main():
         "config": {"workload": f"reference bench.py: {args.num_seqs} requests, prompt U[100,1024], max_tokens U[100,1024], "
                                f"temperature 0.6, ignore_eos, all submitted at once, {args.model} geometry",
                    "geometry": args.model, "ranks": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
-                   "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph"},
+                   "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph",
+                   "run_ahead": eng.run_ahead, "steps_queued_ahead": eng.ahead_steps},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
         "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
         "engine_steps": {k: round(stats1[k] - stats0.get(k, 0), 3) for k in stats1}, "init_s": round(init_s, 1),

@@ -222,7 +222,10 @@ int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_
  * uploaded: step[0] = batch (live rows, <= padded_batch), then four arrays of `stride` entries
  * starting at step[4]: row, pos, slot, token.  For i < batch:
  *   table[row[i]][pos[i]] = slot[i]; kv_start[i] = row[i]*row_capacity; kv_len[i] = pos[i]+1;
- *   out_slots[i] = slot[i]; positions[i] = pos[i]; input_ids[i] = token[i].
+ *   out_slots[i] = slot[i]; positions[i] = pos[i]; input_ids[i] = token[i] -- or, for a negative
+ *   token -1-j, prev_ids[j]: the id the step before sampled for its row j (`prev_ids`, nullable, holds
+ *   at least `stride` ids and is read when the kernel runs, so a step can be queued before the ids of
+ *   the step before have reached the host).
  * For batch <= i < padded_batch (padding rows of a captured graph, attention.py:240-265):
  *   kv_start[i] = pad_start, kv_len[i] = 1, out_slots[i] = -1, positions[i] = input_ids[i] = 0. */
 int nvx_block_table_write_rows(const int32_t* kv_indices, const int32_t* kv_indptr,
@@ -231,7 +234,8 @@ int nvx_block_table_write_rows(const int32_t* kv_indices, const int32_t* kv_indp
 int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_batch,
                           int32_t* table, int64_t n_rows, int64_t row_capacity, int64_t pad_start,
                           int64_t* kv_start, int32_t* kv_len, int64_t* out_slots,
-                          int64_t* positions, int64_t* input_ids, nvx_stream_t stream);
+                          int64_t* positions, int64_t* input_ids, const int64_t* prev_ids,
+                          nvx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,7 @@ SIGNATURES = {
     "nvx_sample": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_vp, _c_i64, _c_vp]),
     "nvx_sampler_probs": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "nvx_block_table_write_rows": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp]),
-    "nvx_decode_step_setup": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "nvx_decode_step_setup": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
 }
 
 _lib = None

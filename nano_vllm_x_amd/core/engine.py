@@ -119,7 +119,8 @@ class Engine(EngineCore):
     def __init__(self, model: str, gpu_memory_utilization: float, max_bs: int, tp_size: int = 1, pp_size: int = 1,
                  nccl_port: int = 29500, device_ids: Optional[list] = None, enforce_eager: bool = False,
                  context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0, prefix_reuse: bool = False,
-                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False):
+                 max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False, chunked_prefill: bool = False,
+                 run_ahead: bool = False):
         from .model_runner import ModelRunner
 
         # pp_size > 1: every rank runs this same engine and scheduler.  Time advances in ticks: at tick t
@@ -139,6 +140,13 @@ class Engine(EngineCore):
                          chunked_prefill=chunked_prefill)
         self.scheduler.on_release = self.model_runner.release_sequence
         self._inflight = None
+        # run_ahead: step_overlapped() queues decode step N+1 behind step N before N's ids have reached the
+        # host, whenever N's outcome cannot change what N+1 is (see _launch_ahead)
+        self.run_ahead = run_ahead and pp_size == 1
+        self._ahead = None            # handle of the step queued behind the one in flight
+        self._placeholders = None     # in-flight step already folded with placeholder tokens: their positions
+        self._late_aborts: list = []
+        self.ahead_steps = 0
         self.pp_size = pp_size
         self._pp_window: deque = deque(maxlen=max(pp_size, 1))   # the batches of the last pp_size ticks, newest last
         self._pp_aborts: list = []
@@ -186,22 +194,79 @@ class Engine(EngineCore):
     def step_overlapped(self) -> list:
         """step() for a driver that keeps the device busy: wait for the step in flight (or run one), fold
         its tokens in, queue the NEXT step, and only then build the output objects -- whatever the host
-        does between the arrival of one step's ids and the launch of the next is time the device idles."""
+        does between the arrival of one step's ids and the launch of the next is time the device idles.
+        With run_ahead the next step is queued even before the wait, where that is possible."""
         if self._inflight is None and not self.begin_step():
             return []
+        if self.run_ahead and self._ahead is None:
+            self._launch_ahead()
         raw = self._finish_inflight()
-        if self.has_unfinished_sequences():
+        if self._inflight is None and self.has_unfinished_sequences():
             self.begin_step()
         return [EngineOutput(*t) for t in raw]
+
+    PLACEHOLDER = -1     # stands in a sequence's token list for an id that is still on the device
+
+    def _launch_ahead(self) -> bool:
+        """Queue decode step N+1 while step N (self._inflight) is running, if N+1 is fully determined
+        without N's ids: N is a graph decode step over ALL running sequences, nothing waits to be
+        admitted, no sequence of N can stop on its token (ignore_eos) or reaches a length limit with it,
+        and the pool has a free slot for each (no eviction, no preemption).  Then N+1 has the same
+        sequences in the same order, one more slot each -- the scheduler is run as usual and must pick
+        exactly that -- and its input ids are N's sampled ids, which the first node of the decode graph
+        reads on the device.  The sequences carry a placeholder for N's token until finish_step(N)."""
+        handle = self._inflight
+        batch = handle[0] if handle is not None else None
+        sched, runner = self.scheduler, self.model_runner
+        if batch is None or self._placeholders is not None or self._late_aborts or not runner.graph_step_possible(batch):
+            return False
+        n = batch.num_seqs
+        if sched.waiting or sched.prefilling or len(sched.running) != n or len(sched.scheduled) != n \
+                or sched.kv_manager.kv_cache_allocator.num_free() < n:
+            return False
+        cap = runner.block_table.row_capacity
+        running = SequenceStatus.RUNNING
+        for seq in batch.seqs:
+            limit = seq.length_limit
+            if limit is None:
+                limit = seq.length_limit = self._length_limit(seq)
+            if seq.status is not running or not seq.sampling_params.ignore_eos or (limit and seq.num_tokens + 1 >= limit) \
+                    or len(seq.kv_indices) + 1 > cap:
+                return False
+        # fold step N with placeholders: what Scheduler.update_sequence does, minus the token's value
+        scheduled = sched.scheduled
+        spots = []
+        for seq in batch.seqs:
+            scheduled.remove(seq.seq_id)
+            seq.cached_kv_len = len(seq.kv_indices)
+            spots.append(len(seq.token_ids))
+            seq.token_ids.append(self.PLACEHOLDER)
+            seq.num_tokens = len(seq.token_ids)
+        nxt = sched.schedule()
+        assert nxt is not None and nxt.forward_mode == batch.forward_mode and len(nxt.seqs) == n \
+            and all(a is b for a, b in zip(nxt.seqs, batch.seqs)), "the step queued ahead must continue the same sequences"
+        self._placeholders = spots
+        self._ahead = runner.launch_step(nxt, ids_on_device=True)
+        self.ahead_steps += 1
+        return True
 
     def _finish_inflight(self) -> list:
         handle, self._inflight = self._inflight, None
         if handle is None:
             return []
         ids = self.model_runner.finish_step(handle)
-        raw = self.fold_output(handle[0], ids) if handle[0] is not None else []
-        if self._pp_aborts:
-            waiting, self._pp_aborts = self._pp_aborts, []
+        if self._placeholders is not None:
+            # folded already, with placeholders: put the ids in; no sequence of such a step finishes with it
+            spots, self._placeholders = self._placeholders, None
+            raw = []
+            for seq, tok, at in zip(handle[0].seqs, ids, spots):
+                seq.token_ids[at] = tok
+                raw.append((seq.seq_id, tok, False, None, seq.prompt_len, at + 1 - seq.prompt_len))
+            self._inflight, self._ahead = self._ahead, None
+        else:
+            raw = self.fold_output(handle[0], ids) if handle[0] is not None else []
+        if self._pp_aborts or self._late_aborts:
+            waiting, self._pp_aborts, self._late_aborts = self._pp_aborts + self._late_aborts, [], []
             for seq_id in waiting:
                 self.abort_sequence(seq_id)
         return raw
@@ -212,17 +277,22 @@ class Engine(EngineCore):
         if self.pp_size > 1 and sequence_id in self.scheduler.scheduled:
             self._pp_aborts.append(sequence_id)
             return
+        if self._placeholders is not None:    # its token list holds a placeholder until the step in flight is back
+            self._late_aborts.append(sequence_id)
+            return
         super().abort_sequence(sequence_id)
 
     @property
     def step_in_flight(self) -> bool:
-        return self._inflight is not None or any(b is not None for b in self._pp_window)
+        return self._inflight is not None or self._ahead is not None or any(b is not None for b in self._pp_window)
 
     def reset(self):
         """Forget every sequence and every cached prefix (fresh scheduler, same pool and graphs)."""
-        if self._inflight is not None:
-            self.model_runner.finish_step(self._inflight)
-            self._inflight = None
+        for handle in (self._inflight, self._ahead):
+            if handle is not None:
+                self.model_runner.finish_step(handle)
+        self._inflight = self._ahead = self._placeholders = None
+        self._late_aborts = []
         while self.pp_size > 1 and self._begin_tick(admit=False):   # drain: every stage must see every batch in flight
             self.end_step()
         for seq_id in list(self.model_runner.block_table.row_of):

@@ -110,7 +110,11 @@ class ModelRunner:
         self.block_table = BlockTable(self.max_bs, n_rows, 2 * self.context_len, self.device)
         self.decode_ws = ops.DecodeWorkspace(self.max_bs, self.num_heads, self.num_kv_heads, self.device)
         self._sample_out = torch.zeros(self.max_bs, dtype=torch.int64, device=self.device)
-        self._sample_host = torch.zeros(self.max_bs, dtype=torch.int64, pin_memory=True)
+        # two pinned landing buffers with an event each: a step queued behind another must not overwrite the
+        # ids the host has not read yet, and the host waits for ITS step's ids, not for the whole stream
+        self._sample_hosts = [torch.zeros(self.max_bs, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        self._sample_events = [torch.cuda.Event() for _ in range(2)]
+        self._sample_turn = 0
         if not self.enforce_eager:
             self.graph = HIPGraph()
             try:
@@ -160,14 +164,21 @@ class ModelRunner:
 
     # -- execution -----------------------------------------------------------------------------------
     @torch.inference_mode()
-    def compute_logits(self, batch: ForwardBatch) -> torch.Tensor:
+    def graph_step_possible(self, batch: ForwardBatch) -> bool:
+        return batch.forward_mode == ForwardMode.DECODE and self.graph is not None and self.graph.is_captured \
+            and batch.num_seqs <= self.graph.max_bs and self.block_table.fits(batch.seqs)
+
+    @torch.inference_mode()
+    def compute_logits(self, batch: ForwardBatch, ids_on_device: bool = False) -> torch.Tensor:
         """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token
-        (None on a pipeline stage other than the last: its output went to the next stage)."""
+        (None on a pipeline stage other than the last: its output went to the next stage).
+        `ids_on_device`: the input ids are the ids the step before sampled, row for row (see launch_step)."""
         decode = batch.forward_mode == ForwardMode.DECODE
-        if decode and self.graph is not None and self.graph.is_captured and batch.num_seqs <= self.graph.max_bs \
-                and self.block_table.fits(batch.seqs):
-            hidden = self._execute_model_graph(batch)
+        if self.graph_step_possible(batch):
+            hidden = self._execute_model_graph(batch, ids_on_device)
             self.stats["graph_steps"] += 1
+        elif ids_on_device:
+            raise RuntimeError("a step that takes its input ids from the device must be a graph decode step")
         else:
             hidden = self._execute_model_eager(batch)
             if decode:
@@ -183,14 +194,19 @@ class ModelRunner:
         return self.finish_step(self.launch_step(batch))
 
     @torch.inference_mode()
-    def launch_step(self, batch: ForwardBatch):
+    def launch_step(self, batch: ForwardBatch, ids_on_device: bool = False):
         """Queue one step on the device (forward, sampling, copy of the sampled ids to pinned memory)
         and return without waiting for it; finish_step() collects the ids.  Between the two the host is
-        free (the engine hands the previous step's tokens to their consumers there)."""
+        free (the engine hands the previous step's tokens to their consumers there).
+
+        `ids_on_device`: this step's sequences are exactly those of the step launched before it, in the
+        same order, and their newest token is whatever that step samples -- not known to the host yet.
+        The first node of the decode graph then takes each row's input id from the sampler's output
+        buffer, so the step can be queued while the one before it is still running."""
         if batch.num_seqs == 0:
             return None
         t0 = time.perf_counter()
-        logits = self.compute_logits(batch)
+        logits = self.compute_logits(batch, ids_on_device)
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
         if logits is None:      # not the last pipeline stage: the ids arrive with the broadcast
@@ -198,10 +214,17 @@ class ModelRunner:
         else:
             ids = self.sampler(logits, temperatures, min_ps, top_ps, top_ks, out=self._sample_out[:n] if n <= self.max_bs else None)
         tpd.broadcast_sampled_ids(ids)
-        if n <= self.max_bs:
-            self._sample_host[:n].copy_(ids, non_blocking=True)
-            ids = None
-        return (batch, ids, t0)
+        return (batch, self._ids_to_host(ids, n), t0)
+
+    def _ids_to_host(self, ids: torch.Tensor, n: int):
+        """Start the copy of a step's ids into the next pinned buffer; returns what finish_step needs."""
+        if n > self.max_bs:
+            return ids
+        self._sample_turn ^= 1
+        k = self._sample_turn
+        self._sample_hosts[k][:n].copy_(ids, non_blocking=True)
+        self._sample_events[k].record()
+        return k
 
     @torch.inference_mode()
     def launch_tick(self, mine: Optional[ForwardBatch], out: Optional[ForwardBatch]):
@@ -229,9 +252,7 @@ class ModelRunner:
             else:
                 ids = self._sample_out[:n] if n <= self.max_bs else torch.empty(n, dtype=torch.int64, device=self.device)
             tpd.broadcast_sampled_ids(ids)
-            if n <= self.max_bs:
-                self._sample_host[:n].copy_(ids, non_blocking=True)
-                ids = None
+            ids = self._ids_to_host(ids, n)
         else:
             out = None
         self.send_stage_output()
@@ -242,9 +263,9 @@ class ModelRunner:
             return []
         batch, ids, t0 = handle
         n = batch.num_seqs
-        if ids is None:
-            torch.cuda.current_stream().synchronize()
-            out = self._sample_host[:n].tolist()
+        if isinstance(ids, int):     # index of the pinned buffer the ids land in
+            self._sample_events[ids].synchronize()
+            out = self._sample_hosts[ids][:n].tolist()
         else:
             out = ids.tolist()
         key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
@@ -289,10 +310,10 @@ class ModelRunner:
         if out is not None:
             tpd.pp_send_next(out)
 
-    def _execute_model_graph(self, batch: ForwardBatch) -> torch.Tensor:
+    def _execute_model_graph(self, batch: ForwardBatch, ids_on_device: bool = False) -> torch.Tensor:
         bs = batch.num_seqs
         padded = self.graph.match_bs(bs)
-        self.block_table.stage_decode_step(batch.seqs)
+        self.block_table.stage_decode_step(batch.seqs, ids_on_device)
         self.graph.replay(padded)
         return self.graph.get_output_buffer("hidden_states")[:bs]
 
@@ -300,7 +321,7 @@ class ModelRunner:
         """The body of a captured decode step for a padded batch of `bs` rows."""
         bt = self.block_table
         ops.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
-                              bt.positions, bt.input_ids)
+                              bt.positions, bt.input_ids, prev_ids=self._sample_out)
         ops.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], self.decode_ws, out_slots=bt.out_slots[:bs])
         wrapper = self._graph_wrappers[bs]
         md = AttentionMetadata(forward_mode=ForwardMode.DECODE, kv_cache=self.kv_cache, output_kv_indices=bt.out_slots[:bs],

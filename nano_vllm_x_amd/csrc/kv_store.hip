@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void decode_step_setup_kernel(
     const int32_t* __restrict__ step, int64_t stride, int64_t padded, int32_t* __restrict__ table,
     int64_t n_rows, int64_t cap, int64_t pad_start, int64_t* __restrict__ kv_start,
     int32_t* __restrict__ kv_len, int64_t* __restrict__ out_slots, int64_t* __restrict__ positions,
-    int64_t* __restrict__ input_ids) {
+    int64_t* __restrict__ input_ids, const int64_t* __restrict__ prev_ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= padded) return;
     int32_t batch = step[0];
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void decode_step_setup_kernel(
         const int32_t row = step[4 + i];
         const int32_t pos = step[4 + stride + i];
         const int32_t slot = step[4 + 2 * stride + i];
-        const int32_t tok = step[4 + 3 * stride + i];
+        int64_t tok = step[4 + 3 * stride + i];
+        // token -1-j: the id sampled for row j of the step before, still on the device
+        if (tok < 0) tok = (prev_ids && -1 - tok < stride) ? prev_ids[-1 - tok] : 0;
         const bool ok = row >= 0 && row < n_rows && pos >= 0 && pos < cap;
         if (ok) table[(int64_t)row * cap + pos] = slot;
         kv_start[i] = ok ? (int64_t)row * cap : pad_start;
@@ -103,7 +105,7 @@ extern "C" int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_
                                      int32_t* table, int64_t n_rows, int64_t row_capacity,
                                      int64_t pad_start, int64_t* kv_start, int32_t* kv_len,
                                      int64_t* out_slots, int64_t* positions, int64_t* input_ids,
-                                     nvx_stream_t stream) {
+                                     const int64_t* prev_ids, nvx_stream_t stream) {
     NVX_REQUIRE(padded_batch > 0 && stride >= padded_batch && n_rows > 0 && row_capacity > 0, NVX_EINVAL,
                 "nvx_decode_step_setup: bad size");
     NVX_REQUIRE(pad_start >= 0 && pad_start < n_rows * row_capacity, NVX_EINVAL,
@@ -113,6 +115,6 @@ extern "C" int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_
     const unsigned blocks = (unsigned)((padded_batch + 255) / 256);
     hipLaunchKernelGGL(decode_step_setup_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, step, stride,
                        padded_batch, table, n_rows, row_capacity, pad_start, kv_start, kv_len, out_slots,
-                       positions, input_ids);
+                       positions, input_ids, prev_ids);
     return nvx_check_launch("nvx_decode_step_setup");
 }

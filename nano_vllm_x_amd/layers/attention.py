@@ -182,8 +182,12 @@ class BlockTable:
         self.positions = torch.zeros(max_bs, dtype=torch.int64, device=device)
         self.input_ids = torch.zeros(max_bs, dtype=torch.int64, device=device)
         self.step_dev = torch.zeros(4 + 4 * max_bs, dtype=torch.int32, device=device)
-        self.step_host = torch.zeros(4 + 4 * max_bs, dtype=torch.int32, pin_memory=(torch.device(device).type == "cuda"))
-        self._step_np = self.step_host.numpy()
+        # two pinned staging buffers, used in turn: with one step queued behind another the upload of the
+        # first may not have run yet when the host fills in the second
+        pin = torch.device(device).type == "cuda"
+        self._step_hosts = [torch.zeros(4 + 4 * max_bs, dtype=torch.int32, pin_memory=pin) for _ in range(2)]
+        self._step_nps = [h.numpy() for h in self._step_hosts]
+        self._step_turn = 0
 
     def assign(self, seq_id: str) -> int:
         if seq_id in self.row_of:
@@ -204,17 +208,23 @@ class BlockTable:
         rows = torch.tensor([self.assign(s.seq_id) for s in seqs], dtype=torch.int32).to(self.device, non_blocking=True)
         ops.block_table_write_rows(kv_indices_dev, kv_indptr_dev, rows, self.table)
 
-    def stage_decode_step(self, seqs):
-        """Fill the pinned step buffer [batch | row | pos | slot | token] and start its upload."""
+    def stage_decode_step(self, seqs, ids_on_device: bool = False):
+        """Fill a pinned step buffer [batch | row | pos | slot | token] and start its upload.  With
+        `ids_on_device` the token of row i is written as -1-i: the id that the step before sampled for its
+        row i (same sequences in the same order) and that has not reached the host yet."""
         n, m = len(seqs), self.max_bs
-        buf = self._step_np
+        self._step_turn ^= 1
+        buf = self._step_nps[self._step_turn]
         buf[0] = n
         row_of = self.row_of
         buf[4:4 + n] = [row_of[s.seq_id] for s in seqs]
         buf[4 + m:4 + m + n] = [len(s.kv_indices) - 1 for s in seqs]
         buf[4 + 2 * m:4 + 2 * m + n] = [s.kv_indices[-1] for s in seqs]
-        buf[4 + 3 * m:4 + 3 * m + n] = [s.token_ids[-1] for s in seqs]
-        self.step_dev.copy_(self.step_host, non_blocking=True)
+        if ids_on_device:
+            buf[4 + 3 * m:4 + 3 * m + n] = np.arange(-1, -1 - n, -1, dtype=np.int32)
+        else:
+            buf[4 + 3 * m:4 + 3 * m + n] = [s.token_ids[-1] for s in seqs]
+        self.step_dev.copy_(self._step_hosts[self._step_turn], non_blocking=True)
 
     def fits(self, seqs) -> bool:
         return all(s.seq_id in self.row_of and len(s.kv_indices) <= self.row_capacity for s in seqs)

@@ -46,11 +46,11 @@ class LLM:
                  pp_size: int = 1, nccl_port: int = 29500, device_ids: Optional[list] = None,
                  enforce_eager: bool = False, context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0,
                  prefix_reuse: bool = False, max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False,
-                 chunked_prefill: bool = False):
+                 chunked_prefill: bool = False, run_ahead: bool = False):
         self.engine = Engine(model, gpu_memory_utilization, max_bs, tp_size, pp_size, nccl_port, device_ids,
                              enforce_eager, context_len, kv_cache_size=kv_cache_size, seed=seed, prefix_reuse=prefix_reuse,
                              max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len,
-                             chunked_prefill=chunked_prefill)
+                             chunked_prefill=chunked_prefill, run_ahead=run_ahead)
         self.tokenizer = init_tokenizer(model)
         self.request_states: dict = {}
         self._pump: Optional[asyncio.Task] = None

@@ -366,8 +366,13 @@ def block_table_write_rows(kv_indices, kv_indptr, rows, table):
                                               table.shape[1], _stream()), "nvx_block_table_write_rows")
 
 
-def decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids):
+def decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids,
+                      prev_ids=None):
+    """`prev_ids` (int64, at least `stride` entries): where a negative token -1-j of the step buffer is looked up."""
     _dev(step, table, kv_start, kv_len, out_slots, positions, input_ids)
+    if prev_ids is not None:
+        _dev(prev_ids)
+        _need(prev_ids.dtype == torch.int64 and prev_ids.numel() >= stride and prev_ids.is_contiguous(), "decode_step_setup: prev_ids")
     _need(step.dtype == torch.int32 and step.numel() >= 4 + 4 * stride and step.is_contiguous(), "decode_step_setup: step buffer")
     _need(table.dim() == 2 and table.is_contiguous() and table.dtype == torch.int32, "decode_step_setup: table")
     _need(kv_len.dtype == torch.int32 and all(x.dtype == torch.int64 for x in (kv_start, out_slots, positions, input_ids)),
@@ -377,4 +382,4 @@ def decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv
     lib = _lib.load()
     _lib.check(lib.nvx_decode_step_setup(_ptr(step), stride, padded_batch, _ptr(table), table.shape[0], table.shape[1], pad_start,
                                          _ptr(kv_start), _ptr(kv_len), _ptr(out_slots), _ptr(positions), _ptr(input_ids),
-                                         _stream()), "nvx_decode_step_setup")
+                                         _ptr(prev_ids) if prev_ids is not None else None, _stream()), "nvx_decode_step_setup")

@@ -386,6 +386,12 @@ def test_block_table_kernels(ops):
     assert kv_len[:4].tolist() == [4, 3, 2, 1]
     assert out_slots[:4].tolist() == [13, 22, 31, -1]          # padded row: scatter skipped (attention.py:263-265)
     assert positions[:4].tolist() == [3, 2, 1, 0] and input_ids[:4].tolist() == [7, 8, 9, 0]
+    # a negative token -1-j stands for the id the step before sampled for its row j, still on the device
+    step[4 + 3 * max_bs:7 + 3 * max_bs] = torch.tensor([-1, 8, -3])
+    prev = torch.arange(100, 100 + max_bs, dtype=torch.int64, device=DEV)
+    ops.decode_step_setup(step.to(DEV), max_bs, 4, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids, prev_ids=prev)
+    torch.cuda.synchronize()
+    assert input_ids[:4].tolist() == [100, 8, 102, 0]
 
 
 def test_bad_arguments_raise(ops):

@@ -122,6 +122,42 @@ def test_llm_generate_api():
     assert res[0][-1].num_prompt_tokens == 4 and res[0][-1].num_generated_tokens == 5
 
 
+def test_run_ahead_generates_the_same_streams():
+    """run_ahead queues decode step N+1 before step N's ids reach the host; its input ids are read on the
+    device from the sampler's output buffer.  Same batches, same rows, same (seed, step) draws: the token
+    streams must be bit-identical to the ordinary loop's, with sampling at temperature 0.8."""
+    import asyncio
+
+    from nano_vllm_x_amd.core.common import SamplingParams
+    from nano_vllm_x_amd.llm import LLM
+    from nano_vllm_x_amd.qwen3 import PRESETS
+
+    PRESETS["tiny-ahead"] = dict(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                 num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                                 tie_word_embeddings=False)
+    rng = np.random.default_rng(12)
+    reqs = [(rng.integers(0, 256, size=int(rng.integers(3, 40))).tolist(), int(rng.integers(2, 30))) for _ in range(11)]
+
+    async def main(ahead):
+        llm = LLM("tiny-ahead", max_bs=8, context_len=128, kv_cache_size=1024, seed=3, run_ahead=ahead)
+
+        async def one(i, prompt, n):
+            sp = SamplingParams(temperature=0.8, ignore_eos=(i != 4), eos_token_id=255, max_new_tokens=n)   # one request may stop on EOS
+            return [o.token_id async for o in llm.generate(list(prompt), sp, sequence_id=f"r{i}")]
+
+        res = await asyncio.gather(*(one(i, p, n) for i, (p, n) in enumerate(reqs)))
+        stats = (llm.engine.ahead_steps, dict(llm.engine.model_runner.stats))
+        llm.shutdown()
+        return res, stats
+
+    plain, (n0, st0) = asyncio.run(main(False))
+    ahead, (n1, st1) = asyncio.run(main(True))
+    assert n0 == 0 and n1 > 0
+    assert st0["decode_steps"] == st1["decode_steps"] and st1["eager_decode_steps"] == 0
+    assert plain == ahead
+    assert [len(r) for r in plain if r] and all(len(r) <= n for r, (_, n) in zip(plain, reqs))
+
+
 def test_prefix_reuse_generates_the_same_tokens_with_fewer_prefill_rows():
     """Requests sharing a cached system prompt: with Scheduler(prefix_reuse=True) the shared rows are
     read from the pool instead of recomputed.  Greedy streams must equal those of the reference-faithful
