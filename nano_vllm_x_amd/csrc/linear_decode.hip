@@ -188,6 +188,101 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     }
 }
 
+// Gate/up projection with SiLU(gate) * up for staged batches, 32 gate rows + the 32 matching up rows per
+// workgroup and the 16-row tiles of X dealt to gridDim.z workgroups per W slice (the same trade as WIDE
+// above: half the activation traffic at the same weight traffic and workgroup count).  64 rows of W over
+// K = 1024 would need 128 KB of LDS beside the 64 KB of staging areas, so W passes through LDS in two
+// halves of K and the accumulators live across them: each wave owns at most ONE tile of X
+// (tiles <= 8 * gridDim.z, checked by the host).
+template <int KC>
+__global__ __launch_bounds__(LIN_THREADS) void linear_gateup_wide_kernel(
+    const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* __restrict__ w, uint16_t* __restrict__ y, int m_rows,
+    int n_rows, int k_total) {
+    constexpr int KPH = 2, KP = KC / KPH;        // K phases, k per phase
+    constexpr int STEPS = KP / 32, GROUPS = KP / 256;
+    constexpr int PIECES_ROW = KP / 8, PIECES_Q = 16 * PIECES_ROW;
+    constexpr int WLOADS = 4 * PIECES_Q / LIN_THREADS;
+    static_assert(KP % 256 == 0, "a phase is a whole number of 256-k groups");
+    __shared__ nvx_u32x4 lds[4 * STEPS * 64];              // quarters: gate rows 0-15, 16-31, up rows 0-15, 16-31
+    __shared__ nvx_u32x4 stage[LIN_WAVES * 16 * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int quad = lane >> 4, l16 = lane & 15;
+    const int n_out = n_rows / 2;
+    const int n0 = blockIdx.x * 32;
+    const int tile = wave * gridDim.z + blockIdx.z;
+    const bool has = tile * 16 < m_rows;
+    nvx_u32x4* my_stage = stage + wave * (16 * 32);
+    nvx_u32x4 b[8];
+    auto load_x = [&](int phase, int group) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int row = tile * 16 + 2 * u + (lane >> 5);
+            row = row < m_rows ? row : m_rows - 1;
+            b[u] = *reinterpret_cast<const nvx_u32x4*>(x + (int64_t)row * x_stride + phase * KP + group * 256 + (lane & 31) * 8);
+        }
+    };
+    if (has) load_x(0, 0);
+    nvx_f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = nvx_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int phase = 0; phase < KPH; ++phase) {
+        if (phase) __syncthreads();           // every wave is done with the previous half of W
+        {
+            nvx_u32x4 v[WLOADS];
+#pragma unroll
+            for (int u = 0; u < WLOADS; ++u) {
+                const int p = u * LIN_THREADS + tid;
+                const int q = p / PIECES_Q, ph = p % PIECES_Q;
+                const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
+                const int row = n0 + (q & 1) * 16 + (q >> 1) * n_out + r;
+                v[u] = *reinterpret_cast<const nvx_u32x4*>(w + (int64_t)row * k_total + phase * KP + kp * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < WLOADS; ++u) {
+                const int p = u * LIN_THREADS + tid;
+                const int q = p / PIECES_Q, ph = p % PIECES_Q;
+                const int r = ph / PIECES_ROW, kp = ph % PIECES_ROW;
+                lds[q * STEPS * 64 + lin_slot(2 * (kp >> 3) + (kp & 1), (kp >> 1) & 3, r)] = v[u];
+            }
+        }
+        __syncthreads();
+        if (has) {
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = 2 * u + (lane >> 5);
+                    my_stage[r * 32 + ((lane & 31) ^ r)] = b[u];
+                }
+                if (g + 1 < GROUPS) load_x(phase, g + 1);
+                else if (phase + 1 < KPH) load_x(phase + 1, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int piece = 8 * (i >> 1) + 2 * quad + (i & 1);
+                    const nvx_u32x4 bf = my_stage[l16 * 32 + (piece ^ l16)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma16(lds[q * STEPS * 64 + lin_slot(g * 8 + i, quad, l16)], bf, acc[q]);
+                }
+            }
+        }
+    }
+    const int row = tile * 16 + l16;
+    if (!has || row >= m_rows) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gate = round_bf16(acc[h][r]), up = round_bf16(acc[2 + h][r]);
+            const float sg = round_bf16(gate / (1.0f + __expf(-gate)));
+            o[r] = sg * up;
+        }
+        uint16_t* dst = y + (int64_t)row * n_out + n0 + h * 16 + quad * 4;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    }
+}
+
 #include <stdlib.h>
 // rows above which the activations go through the LDS staging area (NVX_LIN_STAGED_MIN overrides: tuning)
 static int lin_staged_min_rows() {
@@ -206,6 +301,10 @@ static int lin_env_int(const char* name, int dflt) { const char* e = getenv(name
 // before): the pair halves the X traffic at the same W traffic and the same number of workgroups.
 static int lin_wide_min_rows() { static int v = -1; if (v < 0) v = lin_env_int("NVX_LIN_WIDE_MIN", 1); return v; }
 static int lin_msplit() { static int v = -1; if (v < 0) { v = lin_env_int("NVX_LIN_MSPLIT", 2); if (v < 1 || v > 8) v = 2; } return v; }
+
+// rows from which the gate/up mode uses its 64-row kernel: 64 rows 8.2 vs 7.8 us, 123 rows 9.1 vs 9.7,
+// 176 rows 10.7 vs 12.2, 256 rows 12.3 vs 14.9 (two passes of W through LDS cost a barrier pair)
+static int lin_gateup_wide_min_rows() { static int v = -1; if (v < 0) v = lin_env_int("NVX_LIN_GATEUP_WIDE_MIN", 112); return v; }
 
 static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
 
@@ -242,6 +341,13 @@ extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void
                                                      x_row_stride, (const uint16_t*)w, y, (int)m, (int)n, (int)k)
 #define NVX_LIN_KC(MODE, ST, WD) do { if (kc == 512) NVX_LIN(MODE, 512, ST, WD); else if (kc == 768) NVX_LIN(MODE, 768, ST, WD); else NVX_LIN(MODE, 1024, ST, WD); } while (0)
 #define NVX_LIN_ST(MODE) do { if (staged) NVX_LIN_KC(MODE, true, false); else NVX_LIN_KC(MODE, false, false); } while (0)
+    const int64_t tiles = (m + 15) / 16;
+    if (mode == 1 && staged && lin_gateup_wide_min_rows() > 0 && m >= lin_gateup_wide_min_rows() && kc == 1024 && n_out % 32 == 0 &&
+        (n_out / 32) % 8 == 0 && lin_msplit() == 2 && tiles <= 2 * LIN_WAVES) {
+        hipLaunchKernelGGL((linear_gateup_wide_kernel<1024>), dim3((unsigned)(n_out / 32), 1, 2), dim3(LIN_THREADS), 0, st,
+                           (const uint16_t*)x, x_row_stride, (const uint16_t*)w, (uint16_t*)y, (int)m, (int)n, (int)k);
+        return nvx_check_launch("nvx_linear_decode");
+    }
     if (wide) { if (mode == 0) NVX_LIN_KC(0, true, true); else NVX_LIN_KC(2, true, true); }
     else if (mode == 0) NVX_LIN_ST(0); else if (mode == 1) NVX_LIN_ST(1); else NVX_LIN_ST(2);
 #undef NVX_LIN_ST

@@ -487,9 +487,10 @@ def test_linear_decode_matches_fp32_matmul(ops, m, n, k):
             assert bf16_ulp_diff(ops.rmsnorm_splitk(parts, nw, 1e-6), ops.rmsnorm(parts.sum(0).to(torch.bfloat16), nw, 1e-6)) <= 2
 
 
-def test_linear_decode_strided_input_and_fused_silu(ops):
-    gen = torch.Generator().manual_seed(8)
-    m, k, inter = 37, 1024, 3072
+@pytest.mark.parametrize("m", [37, 49, 64, 123, 200, 256])
+def test_linear_decode_strided_input_and_fused_silu(ops, m):
+    gen = torch.Generator().manual_seed(8 + m)
+    k, inter = 1024, 3072
     wide = torch.randn(m, k + 64, generator=gen).to(torch.bfloat16).to(DEV)
     x = wide[:, :k]                                     # rows 1088 elements apart
     w = (torch.randn(2 * inter, k, generator=gen) * k ** -0.5).to(torch.bfloat16).to(DEV)
