@@ -113,6 +113,7 @@ class EngineCore:
     def update_from_output(self, batch: ForwardBatch, output_ids: list) -> list:
         return [EngineOutput(*t) for t in self.fold_output(batch, output_ids)]
 
+
 class Engine(EngineCore):
     """Engine with the reference's nine constructor arguments (engine.py:13-24, llm.py:17-28)."""
 
