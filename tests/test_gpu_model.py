@@ -122,7 +122,9 @@ def test_llm_generate_api():
     assert res[0][-1].num_prompt_tokens == 4 and res[0][-1].num_generated_tokens == 5
 
 
-def test_run_ahead_generates_the_same_streams():
+@pytest.mark.parametrize("extra", [{}, {"prefix_reuse": True}, {"max_prefill_tokens": 32, "chunked_prefill": True}],
+                         ids=["plain", "prefix_reuse", "chunked_prefill"])
+def test_run_ahead_generates_the_same_streams(extra):
     """run_ahead queues decode step N+1 before step N's ids reach the host; its input ids are read on the
     device from the sampler's output buffer.  Same batches, same rows, same (seed, step) draws: the token
     streams must be bit-identical to the ordinary loop's, with sampling at temperature 0.8."""
@@ -139,7 +141,7 @@ def test_run_ahead_generates_the_same_streams():
     reqs = [(rng.integers(0, 256, size=int(rng.integers(3, 40))).tolist(), int(rng.integers(2, 30))) for _ in range(11)]
 
     async def main(ahead):
-        llm = LLM("tiny-ahead", max_bs=8, context_len=128, kv_cache_size=1024, seed=3, run_ahead=ahead)
+        llm = LLM("tiny-ahead", max_bs=8, context_len=128, kv_cache_size=1024, seed=3, run_ahead=ahead, **extra)
 
         async def one(i, prompt, n):
             sp = SamplingParams(temperature=0.8, ignore_eos=(i != 4), eos_token_id=255, max_new_tokens=n)   # one request may stop on EOS
