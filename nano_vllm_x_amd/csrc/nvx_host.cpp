@@ -17,5 +17,6 @@ int nvx_check_launch(const char* what) {
     return NVX_OK;
 }
 
-extern "C" int nvx_abi_version(void) { return 1; }
+// 2: nvx_decode_step_setup gained `prev_ids`
+extern "C" int nvx_abi_version(void) { return 2; }
 extern "C" const char* nvx_last_error(void) { return nvx_err_buf; }

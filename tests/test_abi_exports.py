@@ -26,6 +26,22 @@ def test_header_declares_what_the_binding_binds():
     assert set(_lib.SIGNATURES) <= set(names), set(_lib.SIGNATURES) - set(names)
 
 
+def test_binding_passes_as_many_arguments_as_the_header_declares():
+    """A prototype that gains a parameter must gain it in the ctypes table too: a missing trailing argument
+    is not an error at the call, the callee just reads a stale register."""
+    from nano_vllm_x_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "nvx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    seen = 0
+    for name, args in re.findall(r"\b(nvx_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        n = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        if name in _lib.SIGNATURES:
+            assert len(_lib.SIGNATURES[name][1]) == n, f"{name}: header declares {n} parameters, binding passes {len(_lib.SIGNATURES[name][1])}"
+            seen += 1
+    assert seen == len(_lib.SIGNATURES)
+
+
 def test_library_exports_every_declared_symbol():
     from nano_vllm_x_amd import _lib
 
