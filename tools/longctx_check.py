@@ -14,8 +14,9 @@ rnd = random.Random(0)
 reqs = [([rnd.randint(0, 10000) for _ in range(rnd.randint(1024, 3072))], rnd.randint(64, 256)) for _ in range(n_req)]
 pool = 150_000        # < sum of final lengths (~430k): several admission waves
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # > 0: chunked prefill with this many tokens per prefill step
+ahead = len(sys.argv) > 4 and sys.argv[4] == "ahead"         # queue decode steps ahead of their input ids
 llm = LLM(model=model, gpu_memory_utilization=0.8, max_bs=256, context_len=4096, kv_cache_size=pool,
-          max_prefill_tokens=chunk or None, chunked_prefill=chunk > 0)
+          max_prefill_tokens=chunk or None, chunked_prefill=chunk > 0, run_ahead=ahead)
 
 
 async def run():
@@ -33,6 +34,6 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 st = llm.engine.model_runner.stats
 print(json.dumps({"model": model, "requests": n_req, "prompt_tokens": sum(len(p) for p, _ in reqs), "generated": gen,
-                  "wall_s": round(wall, 2), "generated_tok_per_s": round(gen / wall, 1), "kv_pool_slots": pool, "prefill_chunk_tokens": chunk,
+                  "wall_s": round(wall, 2), "generated_tok_per_s": round(gen / wall, 1), "kv_pool_slots": pool, "prefill_chunk_tokens": chunk, "steps_queued_ahead": llm.engine.ahead_steps,
                   "engine_steps": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}}))
 llm.shutdown()
