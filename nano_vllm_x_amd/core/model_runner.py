@@ -59,6 +59,7 @@ class ModelRunner:
         self.block_table: Optional[BlockTable] = None
         self._sp_key, self._sp_dev = None, None
         self._stage_output, self._defer_stage_send = None, False
+        self._last_done = 0.0
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
 
     # -- set-up -----------------------------------------------------------------------------------
@@ -269,7 +270,10 @@ class ModelRunner:
         else:
             out = ids.tolist()
         key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
-        self.stats[key] = self.stats.get(key, 0.0) + (time.perf_counter() - t0)   # launch to completion
+        # launch to completion; a step queued behind another is charged from the moment that one completed
+        now = time.perf_counter()
+        self.stats[key] = self.stats.get(key, 0.0) + (now - max(t0, self._last_done))
+        self._last_done = now
         return out
 
     def _execute_model_eager(self, batch: ForwardBatch) -> torch.Tensor:
