@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--max-prefill-tokens", type=int, default=0,
+                    help="> 0: admit prompts in prefill steps of at most this many tokens (0 = one step for the burst, as the reference)")
     ap.add_argument("--run-ahead", type=int, default=1,
                     help="1: queue decode step N+1 before step N's ids reach the host (same batches, same tokens; one rank only)")
     ap.add_argument("--cpu-requests", type=int, default=8)
@@ -227,7 +229,7 @@ def main():
         kv_size = 2_000_000
     llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
               context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size,
-              run_ahead=bool(args.run_ahead) and world == 1)
+              run_ahead=bool(args.run_ahead) and world == 1, max_prefill_tokens=args.max_prefill_tokens or None)
     init_s = time.perf_counter() - t_init
     eng = llm.engine
 
@@ -259,7 +261,8 @@ def main():
                                f"temperature 0.6, ignore_eos, all submitted at once, {args.model} geometry",
                    "geometry": args.model, "ranks": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
                    "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph",
-                   "run_ahead": eng.run_ahead, "steps_queued_ahead": eng.ahead_steps},
+                   "run_ahead": eng.run_ahead, "steps_queued_ahead": eng.ahead_steps,
+                   "max_prefill_tokens": args.max_prefill_tokens or None},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
         "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
         "engine_steps": {k: round(stats1[k] - stats0.get(k, 0), 3) for k in stats1}, "init_s": round(init_s, 1),
