@@ -11,7 +11,8 @@ from nano_vllm_x_amd import LLM
 from nano_vllm_x_amd.core.common import ForwardMode
 
 prompts, max_tokens = bench.workload(256)
-llm = LLM(model="Qwen3-0.6B", gpu_memory_utilization=0.8, max_bs=256, context_len=4096, kv_cache_size=400000)
+ahead = len(sys.argv) > 1 and sys.argv[1] == "ahead"
+llm = LLM(model="Qwen3-0.6B", gpu_memory_utilization=0.8, max_bs=256, context_len=4096, kv_cache_size=400000, run_ahead=ahead)
 runner = llm.engine.model_runner
 asyncio.run(bench.one_pass(llm, prompts, max_tokens))
 llm.engine.reset()
@@ -19,10 +20,10 @@ events = []
 real = runner.launch_step
 
 
-def launch_step(batch):
+def launch_step(batch, ids_on_device=False):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    h = real(batch)
+    h = real(batch, ids_on_device)
     b.record()
     events.append((a, b, batch.forward_mode, batch.num_seqs))
     return h
