@@ -147,7 +147,8 @@ class Engine(EngineCore):
         self._ahead = None            # handle of the step queued behind the one in flight
         self._placeholders = None     # in-flight step already folded with placeholder tokens: their positions
         self._late_aborts: list = []
-        self.ahead_steps = 0
+        self.ahead_steps = 0         # steps queued ahead
+        self.ahead_retired = 0       # sequences retired by a step that had another queued behind it
         self.pp_size = pp_size
         self._pp_window: deque = deque(maxlen=max(pp_size, 1))   # the batches of the last pp_size ticks, newest last
         self._pp_aborts: list = []
@@ -211,8 +212,11 @@ class Engine(EngineCore):
     def _launch_ahead(self) -> bool:
         """Queue decode step N+1 while step N (self._inflight) is running, if N+1 is fully determined
         without N's ids: N is a graph decode step over ALL running sequences, nothing waits to be
-        admitted, no sequence of N can stop on its token (ignore_eos) or reaches a length limit with it,
-        and the pool has a free slot for each (no eviction, no preemption).  Then N+1 has the same
+        admitted, no sequence of N can stop on its token (ignore_eos), and the pool has a free slot for
+        every sequence that goes on (no eviction, no preemption).  Sequences that reach a length limit
+        with N's token leave the queues now and are retired when the token is in place (the retirement
+        only feeds the prefix tree, which nothing reads or evicts from in between; with prefix_reuse it
+        could also free slots, so such steps are not queued ahead then).  N+1 has the remaining
         sequences in the same order, one more slot each -- the scheduler is run as usual and must pick
         exactly that -- and its input ids are N's sampled ids, which the first node of the decode graph
         reads on the device.  The sequences carry a placeholder for N's token until finish_step(N)."""
@@ -222,32 +226,41 @@ class Engine(EngineCore):
         if batch is None or self._placeholders is not None or self._late_aborts or not runner.graph_step_possible(batch):
             return False
         n = batch.num_seqs
-        if sched.waiting or sched.prefilling or len(sched.running) != n or len(sched.scheduled) != n \
-                or sched.kv_manager.kv_cache_allocator.num_free() < n:
+        if sched.waiting or sched.prefilling or len(sched.running) != n or len(sched.scheduled) != n:
             return False
         cap = runner.block_table.row_capacity
         running = SequenceStatus.RUNNING
-        for seq in batch.seqs:
+        rows_on, leaving = [], set()
+        for j, seq in enumerate(batch.seqs):
             limit = seq.length_limit
             if limit is None:
                 limit = seq.length_limit = self._length_limit(seq)
-            if seq.status is not running or not seq.sampling_params.ignore_eos or (limit and seq.num_tokens + 1 >= limit) \
-                    or len(seq.kv_indices) + 1 > cap:
+            if seq.status is not running or not seq.sampling_params.ignore_eos:
                 return False
+            if limit and seq.num_tokens + 1 >= limit:
+                leaving.add(j)
+            elif len(seq.kv_indices) + 1 > cap:
+                return False
+            else:
+                rows_on.append(j)
+        if not rows_on or (leaving and self.prefix_reuse) or sched.kv_manager.kv_cache_allocator.num_free() < len(rows_on):
+            return False
         # fold step N with placeholders: what Scheduler.update_sequence does, minus the token's value
         scheduled = sched.scheduled
         spots = []
-        for seq in batch.seqs:
+        for j, seq in enumerate(batch.seqs):
             scheduled.remove(seq.seq_id)
             seq.cached_kv_len = len(seq.kv_indices)
             spots.append(len(seq.token_ids))
             seq.token_ids.append(self.PLACEHOLDER)
             seq.num_tokens = len(seq.token_ids)
+            if j in leaving:
+                sched.detach_finishing(seq)
         nxt = sched.schedule()
-        assert nxt is not None and nxt.forward_mode == batch.forward_mode and len(nxt.seqs) == n \
-            and all(a is b for a, b in zip(nxt.seqs, batch.seqs)), "the step queued ahead must continue the same sequences"
-        self._placeholders = spots
-        self._ahead = runner.launch_step(nxt, ids_on_device=True)
+        assert nxt is not None and nxt.forward_mode == batch.forward_mode and len(nxt.seqs) == len(rows_on) \
+            and all(a is batch.seqs[j] for a, j in zip(nxt.seqs, rows_on)), "the step queued ahead must continue the same sequences"
+        self._placeholders = (spots, leaving)
+        self._ahead = runner.launch_step(nxt, ids_on_device=rows_on)
         self.ahead_steps += 1
         return True
 
@@ -257,12 +270,17 @@ class Engine(EngineCore):
             return []
         ids = self.model_runner.finish_step(handle)
         if self._placeholders is not None:
-            # folded already, with placeholders: put the ids in; no sequence of such a step finishes with it
-            spots, self._placeholders = self._placeholders, None
+            # folded already, with placeholders: put the ids in and retire the sequences that were known to end here
+            (spots, leaving), self._placeholders = self._placeholders, None
             raw = []
-            for seq, tok, at in zip(handle[0].seqs, ids, spots):
+            for j, (seq, tok, at) in enumerate(zip(handle[0].seqs, ids, spots)):
                 seq.token_ids[at] = tok
-                raw.append((seq.seq_id, tok, False, None, seq.prompt_len, at + 1 - seq.prompt_len))
+                if j in leaving:
+                    self.scheduler.finish_sequence(seq, detached=True)
+                    self.ahead_retired += 1
+                    raw.append((seq.seq_id, tok, True, FinishReason.LENGTH, seq.prompt_len, at + 1 - seq.prompt_len))
+                else:
+                    raw.append((seq.seq_id, tok, False, None, seq.prompt_len, at + 1 - seq.prompt_len))
             self._inflight, self._ahead = self._ahead, None
         else:
             raw = self.fold_output(handle[0], ids) if handle[0] is not None else []

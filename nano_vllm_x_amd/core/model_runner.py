@@ -170,15 +170,15 @@ class ModelRunner:
             and batch.num_seqs <= self.graph.max_bs and self.block_table.fits(batch.seqs)
 
     @torch.inference_mode()
-    def compute_logits(self, batch: ForwardBatch, ids_on_device: bool = False) -> torch.Tensor:
+    def compute_logits(self, batch: ForwardBatch, ids_on_device=None) -> torch.Tensor:
         """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token
         (None on a pipeline stage other than the last: its output went to the next stage).
-        `ids_on_device`: the input ids are the ids the step before sampled, row for row (see launch_step)."""
+        `ids_on_device`: the input ids are ids the step before sampled (see launch_step)."""
         decode = batch.forward_mode == ForwardMode.DECODE
         if self.graph_step_possible(batch):
             hidden = self._execute_model_graph(batch, ids_on_device)
             self.stats["graph_steps"] += 1
-        elif ids_on_device:
+        elif ids_on_device is not None:
             raise RuntimeError("a step that takes its input ids from the device must be a graph decode step")
         else:
             hidden = self._execute_model_eager(batch)
@@ -195,15 +195,15 @@ class ModelRunner:
         return self.finish_step(self.launch_step(batch))
 
     @torch.inference_mode()
-    def launch_step(self, batch: ForwardBatch, ids_on_device: bool = False):
+    def launch_step(self, batch: ForwardBatch, ids_on_device=None):
         """Queue one step on the device (forward, sampling, copy of the sampled ids to pinned memory)
         and return without waiting for it; finish_step() collects the ids.  Between the two the host is
         free (the engine hands the previous step's tokens to their consumers there).
 
-        `ids_on_device`: this step's sequences are exactly those of the step launched before it, in the
-        same order, and their newest token is whatever that step samples -- not known to the host yet.
-        The first node of the decode graph then takes each row's input id from the sampler's output
-        buffer, so the step can be queued while the one before it is still running."""
+        `ids_on_device` (a list: for every sequence of this batch, its row in the step launched before it):
+        the sequences' newest token is whatever that step samples -- not known to the host yet.  The first
+        node of the decode graph then takes each row's input id from the sampler's output buffer, so the
+        step can be queued while the one before it is still running."""
         if batch.num_seqs == 0:
             return None
         t0 = time.perf_counter()
@@ -314,7 +314,7 @@ class ModelRunner:
         if out is not None:
             tpd.pp_send_next(out)
 
-    def _execute_model_graph(self, batch: ForwardBatch, ids_on_device: bool = False) -> torch.Tensor:
+    def _execute_model_graph(self, batch: ForwardBatch, ids_on_device=None) -> torch.Tensor:
         bs = batch.num_seqs
         padded = self.graph.match_bs(bs)
         self.block_table.stage_decode_step(batch.seqs, ids_on_device)

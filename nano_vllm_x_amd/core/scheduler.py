@@ -267,11 +267,20 @@ class Scheduler:
         seq.token_ids.append(new_token_id)
         seq.num_tokens = len(seq.token_ids)
 
-    def finish_sequence(self, seq: Sequence):
+    def detach_finishing(self, seq: Sequence):
+        """First half of finish_sequence for a running sequence whose last token is known to be its last but
+        not yet known by value: it leaves `running` now (the next step is scheduled without it) and
+        finish_sequence(seq, detached=True) does the rest once the token is in place."""
+        self.running.remove(seq)
+        self.scheduled.discard(seq.seq_id)
+
+    def finish_sequence(self, seq: Sequence, detached: bool = False):
         """Retire a sequence; its tokens and slots go to the prefix tree (scheduler.py:173-190)."""
         if seq.status == SequenceStatus.FINISHED:
             return
-        if seq.status == SequenceStatus.WAITING:
+        if detached:
+            pass                      # already off the queues (detach_finishing)
+        elif seq.status == SequenceStatus.WAITING:
             self.waiting.remove(seq)
         elif seq.status == SequenceStatus.RUNNING:
             self.running.remove(seq)

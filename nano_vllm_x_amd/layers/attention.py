@@ -208,10 +208,10 @@ class BlockTable:
         rows = torch.tensor([self.assign(s.seq_id) for s in seqs], dtype=torch.int32).to(self.device, non_blocking=True)
         ops.block_table_write_rows(kv_indices_dev, kv_indptr_dev, rows, self.table)
 
-    def stage_decode_step(self, seqs, ids_on_device: bool = False):
+    def stage_decode_step(self, seqs, ids_on_device=None):
         """Fill a pinned step buffer [batch | row | pos | slot | token] and start its upload.  With
-        `ids_on_device` the token of row i is written as -1-i: the id that the step before sampled for its
-        row i (same sequences in the same order) and that has not reached the host yet."""
+        `ids_on_device` (a list: for every sequence its row in the step before) the token of a row is
+        written as -1-j: the id that step sampled for its row j and that has not reached the host yet."""
         n, m = len(seqs), self.max_bs
         self._step_turn ^= 1
         buf = self._step_nps[self._step_turn]
@@ -220,8 +220,8 @@ class BlockTable:
         buf[4:4 + n] = [row_of[s.seq_id] for s in seqs]
         buf[4 + m:4 + m + n] = [len(s.kv_indices) - 1 for s in seqs]
         buf[4 + 2 * m:4 + 2 * m + n] = [s.kv_indices[-1] for s in seqs]
-        if ids_on_device:
-            buf[4 + 3 * m:4 + 3 * m + n] = np.arange(-1, -1 - n, -1, dtype=np.int32)
+        if ids_on_device is not None:
+            buf[4 + 3 * m:4 + 3 * m + n] = [-1 - j for j in ids_on_device]
         else:
             buf[4 + 3 * m:4 + 3 * m + n] = [s.token_ids[-1] for s in seqs]
         self.step_dev.copy_(self._step_hosts[self._step_turn], non_blocking=True)

@@ -208,7 +208,7 @@ def _fake_engine(pp_rank: int, pp: int, monkeypatch):
     EngineCore.__init__(eng, kv_cache_size=4096, max_bs=2, context_len=256)
     eng.model_runner = _FakeRunner()
     eng._inflight, eng.pp_size, eng._pp_window, eng._pp_aborts = None, pp, deque(maxlen=pp), []
-    eng.run_ahead, eng._ahead, eng._placeholders, eng._late_aborts, eng.ahead_steps = False, None, None, [], 0
+    eng.run_ahead, eng._ahead, eng._placeholders, eng._late_aborts, eng.ahead_steps, eng.ahead_retired = False, None, None, [], 0, 0
     eng.pp_stats = {"ticks": 0, "stage_busy_ticks": 0}
     return eng
 

@@ -34,15 +34,18 @@ class _Runner:
     def graph_step_possible(self, batch):
         return batch.forward_mode == ForwardMode.DECODE
 
-    def launch_step(self, batch, ids_on_device=False):
+    def launch_step(self, batch, ids_on_device=None):
         self.pending += 1
         assert self.pending <= 2
         ids = [(sum(map(ord, s.seq_id)) * 31 + len(s.token_ids) * 7) % 1000 for s in batch.seqs]
-        if ids_on_device:
+        if ids_on_device is not None:
             assert all(s.token_ids[-1] == Engine.PLACEHOLDER for s in batch.seqs)
+            assert [self.last_batch[j] for j in ids_on_device] == [s.seq_id for s in batch.seqs]     # rows of the step before
         else:
             assert all(t >= 0 for s in batch.seqs for t in s.token_ids)
-        self.log.append((batch.forward_mode, [(s.seq_id, len(s.token_ids), tuple(s.kv_indices)) for s in batch.seqs], ids_on_device))
+        self.last_batch = [s.seq_id for s in batch.seqs]
+        self.log.append((batch.forward_mode, [(s.seq_id, len(s.token_ids), tuple(s.kv_indices)) for s in batch.seqs],
+                         ids_on_device is not None))
         return (batch, ids, 0.0)
 
     def finish_step(self, handle):
@@ -59,6 +62,7 @@ def _engine(run_ahead: bool, kv: int = 4096) -> Engine:
     eng.model_runner = _Runner()
     eng._inflight = eng._ahead = eng._placeholders = None
     eng._late_aborts, eng._pp_aborts, eng.ahead_steps = [], [], 0
+    eng.ahead_retired = 0
     eng.run_ahead, eng.pp_size, eng._pp_window = run_ahead, 1, deque(maxlen=1)
     eng.pp_stats = {"ticks": 0, "stage_busy_ticks": 0}
     return eng
@@ -102,6 +106,8 @@ def test_run_ahead_changes_nothing_but_the_launch_order(case):
         eng = _engine(ahead, kv)
         got = _drive(eng, REQS, **kw)
         runs.append((got, eng.model_runner.log, eng.ahead_steps, eng.scheduler.kv_manager.kv_cache_allocator.num_free()))
+        if ahead and case == "plain":
+            assert eng.ahead_retired > 0        # steps after which a sequence ends by length are queued ahead too
         for s in eng.scheduler.sequences.values():
             assert Engine.PLACEHOLDER not in s.token_ids
     (got0, log0, ahead0, free0), (got1, log1, ahead1, free1) = runs
