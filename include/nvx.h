@@ -35,6 +35,12 @@ extern "C" {
 
 typedef void* nvx_stream_t;
 
+/* The one definition of the ABI version: nvx_abi_version() returns it, and the Python binding
+ * (nano_vllm_x_amd/_lib.py) reads this line and refuses a library built from another header.
+ * Bump it whenever a signature below changes.
+ *   2: nvx_decode_step_setup gained `prev_ids`. */
+#define NVX_ABI_VERSION 2
+
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
 const char* nvx_last_error(void);

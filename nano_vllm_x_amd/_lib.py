@@ -8,8 +8,21 @@ from __future__ import annotations
 import ctypes
 import os
 
+import re
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvx_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvx.h")
+
+
+def header_abi_version() -> int:
+    """NVX_ABI_VERSION as include/nvx.h defines it: the version this binding's SIGNATURES table is written for."""
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+NVX_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if m is None:
+        raise NvxLibraryError(f"{HEADER_PATH} does not define NVX_ABI_VERSION")
+    return int(m.group(1))
+
 
 _c_i64, _c_i32, _c_f32, _c_vp, _c_u64 = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
 
@@ -68,6 +81,10 @@ def load():
             raise NvxLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    want, got = header_abi_version(), lib.nvx_abi_version()
+    if got != want:
+        raise NvxLibraryError(f"{LIB_PATH} reports ABI version {got}, include/nvx.h declares {want}: rebuild it "
+                              "(`make -C nano_vllm_x_amd/csrc`)")
     _lib = lib
     return lib
 

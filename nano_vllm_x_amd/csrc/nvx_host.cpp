@@ -17,6 +17,5 @@ int nvx_check_launch(const char* what) {
     return NVX_OK;
 }
 
-// 2: nvx_decode_step_setup gained `prev_ids`
-extern "C" int nvx_abi_version(void) { return 2; }
+extern "C" int nvx_abi_version(void) { return NVX_ABI_VERSION; }
 extern "C" const char* nvx_last_error(void) { return nvx_err_buf; }

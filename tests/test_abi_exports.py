@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/nvx.h but not exported"
     lib.nvx_abi_version.restype = ctypes.c_int
-    assert lib.nvx_abi_version() >= 1
+    assert lib.nvx_abi_version() == _lib.header_abi_version(), "library built from another include/nvx.h: rebuild"
     # pure host helpers answer without a device
     lib.nvx_decode_plan_ws_ints.restype = ctypes.c_int64
     lib.nvx_decode_plan_ws_ints.argtypes = [ctypes.c_int64, ctypes.c_int]
@@ -70,3 +70,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "absent.so" in str(e) or "build" in str(e).lower()
     else:
         raise AssertionError("loading a missing library must raise")
+
+
+def test_build_entry_point_runs_end_to_end():
+    """`python __graft_entry__.py` is the documented build command: it must compile (a no-op when the objects
+    are current), load the library and agree with it on the ABI version."""
+    import __graft_entry__ as g
+
+    g.build()
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    from nano_vllm_x_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "header_abi_version", lambda: 10 ** 6)
+    try:
+        _lib.load()
+    except _lib.NvxLibraryError as e:
+        assert "ABI version" in str(e)
+    else:
+        raise AssertionError("a version mismatch must raise")
