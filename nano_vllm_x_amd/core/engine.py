@@ -316,6 +316,7 @@ class Engine(EngineCore):
             self.end_step()
         for seq_id in list(self.model_runner.block_table.row_of):
             self.model_runner.block_table.release(seq_id)
+        self.model_runner._sp_key = None
         self.scheduler = Scheduler(kv_cache_size=self.kv_cache_size, max_bs=self.scheduler.max_bs, prefix_reuse=self.prefix_reuse,
                                    max_prefill_tokens=self.max_prefill_tokens, chunked_prefill=self.chunked_prefill)
         self.scheduler.on_release = self.model_runner.release_sequence

@@ -141,9 +141,11 @@ class ModelRunner:
     def prepare_sampling_params(self, batch: ForwardBatch):
         """One (4, B) fp32 upload: temperature, min_p, top_p, top_k (-1 -> vocabulary size,
         model_runner.py:202-206).  Returns the four per-row device tensors.  A sequence's parameters never
-        change, so the upload is skipped while the batch holds the same sequences as the step before."""
-        key = tuple(s.seq_id for s in batch.seqs)
-        if key == self._sp_key:
+        change, so the upload is skipped while the batch holds the same parameter objects, in the same order,
+        as the step before (sequence ids do not identify them: a caller may reuse an id for a new request)."""
+        key = [s.sampling_params for s in batch.seqs]    # the objects themselves: an id string can be reused
+        old = self._sp_key
+        if old is not None and len(old) == len(key) and all(a is b for a, b in zip(old, key)):
             return self._sp_dev
         v = self.hf_config.vocab_size
         n = batch.num_seqs
@@ -281,15 +283,12 @@ class ModelRunner:
         md = self.attn_backend.build_metadata(batch)
         with attention_kv_cache(self.model, md):
             hidden = self.model(input_ids, positions) if self.pp_size == 1 else self._run_stage(input_ids, positions)
-        # keep the device block table in step with what the scheduler decided
-        t = self.attn_backend.last_table
-        if batch.forward_mode == ForwardMode.PREFILL:
-            if all(len(s.kv_indices) <= self.block_table.row_capacity for s in batch.seqs) \
-                    and len(self.block_table.free_rows) >= batch.num_seqs:
-                self.block_table.write_prefilled(batch.seqs, t["paged_kv_indices"], t["paged_kv_indptr"])
-        else:
-            for s in batch.seqs:   # a decode step that ran eagerly: its row (if any) is now stale
-                self.block_table.release(s.seq_id)
+        # keep the device block table in step with what the scheduler decided: rows are (re)written from the
+        # step's own slot lists, sequence by sequence, so a decode step that had to run outside the graph
+        # (no free row, a list longer than a row) does not keep its batch off the graph path afterwards
+        if self.graph is not None:
+            t = self.attn_backend.last_table
+            self.block_table.write_rows(batch.seqs, t["paged_kv_indices"], t["paged_kv_indptr"])
         return hidden
 
     def _run_stage(self, input_ids: torch.Tensor, positions: torch.Tensor) -> Optional[torch.Tensor]:

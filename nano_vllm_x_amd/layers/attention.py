@@ -203,10 +203,25 @@ class BlockTable:
         if r is not None:
             self.free_rows.append(r)
 
-    def write_prefilled(self, seqs, kv_indices_dev, kv_indptr_dev):
-        """After a prefill: give every sequence of the batch a row holding its slot list."""
-        rows = torch.tensor([self.assign(s.seq_id) for s in seqs], dtype=torch.int32).to(self.device, non_blocking=True)
-        ops.block_table_write_rows(kv_indices_dev, kv_indptr_dev, rows, self.table)
+    def write_rows(self, seqs, kv_indices_dev, kv_indptr_dev):
+        """After a step that ran from a CSR table (a prefill, or a decode step outside the graph): every
+        sequence of the batch that has, or can get, a row long enough for its slot list gets the list
+        written there; any other sequence loses its row, so that fits() is False for it and its next
+        decode step runs from a CSR table again instead of reading a row nobody filled.  A chunk view (a
+        prompt cut before its end) gets no row: its sequence receives one with its last chunk, whose slot
+        list is the whole prompt's."""
+        rows = []
+        for s in seqs:
+            if s.partial_of is not None:
+                rows.append(-1)
+            elif len(s.kv_indices) <= self.row_capacity and (s.seq_id in self.row_of or self.free_rows):
+                rows.append(self.assign(s.seq_id))
+            else:
+                self.release(s.seq_id)
+                rows.append(-1)
+        if any(r >= 0 for r in rows):   # the kernel skips negative rows
+            ops.block_table_write_rows(kv_indices_dev, kv_indptr_dev,
+                                       torch.tensor(rows, dtype=torch.int32).to(self.device, non_blocking=True), self.table)
 
     def stage_decode_step(self, seqs, ids_on_device=None):
         """Fill a pinned step buffer [batch | row | pos | slot | token] and start its upload.  With

@@ -227,10 +227,16 @@ class VocabParallelEmbedding(nn.Module):
         return tpd.tp_all_reduce(out)
 
 
-def stage_layer_range(num_layers: int, pp_rank: int, pp_size: int):
-    """[start, end) of the decoder layers a pipeline stage holds: an even split, the remainder going to
-    the LAST stages one layer each (the first stage also holds the embedding)."""
+def stage_layer_range(num_layers: int, pp_rank: int, pp_size: int, balanced: bool = False):
+    """[start, end) of the decoder layers a pipeline stage holds.  Default: the reference's split
+    (distributed/utils.py:10-15) -- num_layers // pp_size layers per stage, the LAST stage taking the whole
+    remainder (11 layers over 3 stages: 3, 3, 5).  `balanced=True` (env NVX_PP_BALANCED=1 when the model is
+    built) spreads the remainder one layer each over the last stages instead (3, 4, 4): the longest stage
+    sets the pipeline's step time.  Both agree whenever pp_size divides num_layers."""
     base, extra = divmod(num_layers, pp_size)
+    if not balanced:
+        start = pp_rank * base
+        return start, (num_layers if pp_rank == pp_size - 1 else start + base)
     sizes = [base + (1 if s >= pp_size - extra else 0) for s in range(pp_size)]
     start = sum(sizes[:pp_rank])
     return start, start + sizes[pp_rank]
@@ -249,7 +255,8 @@ class Qwen3Model(nn.Module):
         super().__init__()
         self.config = cfg
         first, last = tpd.pp_is_first(), tpd.pp_is_last()
-        self.start_layer, self.end_layer = stage_layer_range(cfg.num_hidden_layers, tpd.pp_rank(), tpd.pp_size())
+        self.start_layer, self.end_layer = stage_layer_range(cfg.num_hidden_layers, tpd.pp_rank(), tpd.pp_size(),
+                                                             balanced=os.environ.get("NVX_PP_BALANCED") == "1")
         # tied weights: the last stage needs the embedding matrix for its LM head
         self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size) \
             if first or (last and cfg.tie_word_embeddings) else MissingLayer()

@@ -57,18 +57,31 @@ def _run(fn_name: str, tp: int, pp: int):
         assert err is None, f"rank {rank} failed:\n{err}"
 
 
+def _ref_pp_indices(num_layers, pp_rank, pp_size):
+    """nanovllmx/distributed/utils.py:10-15, restated: floor(n/pp) layers each, the last stage the rest."""
+    per = num_layers // pp_size
+    return pp_rank * per, (num_layers if pp_rank == pp_size - 1 else (pp_rank + 1) * per)
+
+
 def test_stage_layer_ranges_cover_every_layer_once():
     from nano_vllm_x_amd.qwen3 import stage_layer_range
 
-    for layers in (1, 2, 3, 28, 36, 64, 65):
+    for layers in (1, 2, 3, 11, 28, 36, 64, 65):
         for pp in (1, 2, 3, 4, 8):
             if pp > layers:
                 continue
-            spans = [stage_layer_range(layers, r, pp) for r in range(pp)]
-            assert spans[0][0] == 0 and spans[-1][1] == layers
-            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-            sizes = [e - s for s, e in spans]
-            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes)   # the first stage (embedding) is never the larger
+            for balanced in (False, True):
+                spans = [stage_layer_range(layers, r, pp, balanced=balanced) for r in range(pp)]
+                assert spans[0][0] == 0 and spans[-1][1] == layers
+                assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+                sizes = [e - s for s, e in spans]
+                assert sizes == sorted(sizes)   # the first stage (embedding) is never the larger
+                if balanced:
+                    assert max(sizes) - min(sizes) <= 1
+                else:   # the default is the reference's split, stage by stage
+                    assert spans == [_ref_pp_indices(layers, r, pp) for r in range(pp)]
+    assert [stage_layer_range(11, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 11)]
+    assert [stage_layer_range(11, r, 3, balanced=True) for r in range(3)] == [(0, 3), (3, 7), (7, 11)]
     assert stage_layer_range(64, 1, 2) == (32, 64)
 
 
