@@ -15,8 +15,10 @@ Also in the JSON line:
                    captured steps launch), replayed on the decode batches of this workload with HIP
                    events on the launch stream; algorithmic bytes = kv_rows * 2 (K,V) * kv_heads * 128 *
                    2 B + raw projection rows in + output rows + 4 B per block-table entry.
-  cpu_baseline  -- the CPU oracle engine (oracle/, a port of the same path) on a bounded sample of the
-                   same workload, timed on this box's host cores (rank 0, N = 1 only).
+  cpu_baseline  -- the CPU oracle engine (oracle/, a port of the same path) timed on this box's host cores
+                   (rank 0, N = 1 only): configuration 1 in full (4 requests, 128 + 128 tokens), with the
+                   device's rate on the same four requests beside it, and a bounded subset of the headline
+                   workload as a second figure.
 """
 from __future__ import annotations
 
@@ -171,21 +173,71 @@ def _pmc_traffic(kernel: str):
     return None
 
 
-def cpu_baseline(prompts, max_tokens, n_req: int, new_tokens: int):
-    """Oracle engine on host cores over the first `n_req` requests, generation capped to `new_tokens`."""
-    from nano_vllm_x_amd.qwen3 import PRESETS, Qwen3Config
-    from oracle.qwen3_oracle import cpu_engine_run_oracle
+def config1_workload():
+    """BASELINE configuration 1: 4 requests, 128 random prompt tokens, 128 new tokens each."""
+    rnd = random.Random(1)
+    return [[rnd.randint(0, 10000) for _ in range(128)] for _ in range(4)], 128
 
-    cfg = Qwen3Config(**PRESETS["Qwen3-0.6B"]).__dict__
-    ps = prompts[:n_req]
-    ms = [min(m, len(p) + new_tokens) for p, m in zip(ps, max_tokens[:n_req])]
-    r = cpu_engine_run_oracle(cfg, ps, ms, kv_slots=sum(max(m, len(p) + 1) for p, m in zip(ps, ms)) + 64, max_bs=256, context_len=4096, dtype=torch.float32)
-    return {"value": round(r["nominal_tokens"] / r["wall_s"], 2), "unit": "tokens/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"first {n_req} requests of the same workload, max_tokens capped at prompt+{new_tokens}; fp32 weights; "
+
+def config1_on_gpu(llm):
+    """Configuration 1 through LLM.generate on the device (arg-max-equivalent sampling), for the figure that
+    stands beside the CPU engine's."""
+    from nano_vllm_x_amd import SamplingParams
+
+    prompts, n_new = config1_workload()
+    llm.engine.reset()
+
+    async def run():
+        async def one(i, p):
+            n = 0
+            async for _ in llm.generate(list(p), SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=n_new),
+                                        sequence_id=f"cfg1-{i}"):
+                n += 1
+            return n
+        return sum(await asyncio.gather(*(one(i, p) for i, p in enumerate(prompts))))
+
+    asyncio.run(run())            # once untimed: first use of the small-batch graphs
+    llm.engine.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = asyncio.run(run())
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
+def cpu_baseline(prompts, max_tokens, n_req: int, new_tokens: int, gpu_config1_tok_s=None):
+    """The CPU engine (oracle/: the same scheduler, block tables, attention, norms and sampling rule restated
+    for the host) on this box's cores.  `value`: configuration 1 in full (4 requests, 128 + 128 tokens, fp32
+    arithmetic on the same bf16-representable weights the device holds, arg-max sampling).  `bench_subset`: the
+    first `n_req` requests of the headline workload with generation capped, as a second figure."""
+    from nano_vllm_x_amd.qwen3 import PRESETS, Qwen3Config, random_checkpoint
+    from oracle.qwen3_oracle import cpu_engine_greedy_oracle, cpu_engine_run_oracle
+
+    cfg_obj = Qwen3Config(**PRESETS["Qwen3-0.6B"])
+    cfg = cfg_obj.__dict__
+    c1_prompts, c1_new = config1_workload()
+    sd = {k: v.to(torch.bfloat16).float() for k, v in random_checkpoint(cfg_obj, 0)}
+    c1 = cpu_engine_greedy_oracle(cfg, sd, c1_prompts, [c1_new] * len(c1_prompts), kv_slots=4 * 257 + 8, max_bs=4,
+                                  context_len=4096, keep_logits=False)
+    del sd
+    out = {"value": round(c1["generated"] / c1["wall_s"], 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"configuration 1 in full: 4 requests x (128 prompt + 128 new tokens), Qwen3-0.6B geometry, fp32 arithmetic, "
+                     f"arg-max sampling; {c1['steps']} engine steps, {c1['generated']} generated tokens in {c1['wall_s']:.1f} s "
+                     f"(prefill {c1['prefill_s']:.2f} s, decode {c1['decode_s']:.1f} s)",
+           "host_cpus": os.cpu_count()}
+    if gpu_config1_tok_s is not None:
+        out["same_sample_on_the_gpu_tokens_per_s"] = round(gpu_config1_tok_s, 1)
+    if n_req > 0:
+        ps = prompts[:n_req]
+        ms = [min(m, len(p) + new_tokens) for p, m in zip(ps, max_tokens[:n_req])]
+        r = cpu_engine_run_oracle(cfg, ps, ms, kv_slots=sum(max(m, len(p) + 1) for p, m in zip(ps, ms)) + 64, max_bs=256,
+                                  context_len=4096, dtype=torch.float32)
+        out["bench_subset"] = {
+            "value": round(r["nominal_tokens"] / r["wall_s"], 2), "unit": "tokens/s (bench.py-nominal)",
+            "sample": f"first {n_req} requests of the headline workload, max_tokens capped at prompt+{new_tokens}; fp32 weights; "
                       f"{r['steps']} engine steps, {r['generated']} generated tokens, {r['wall_s']:.1f} s wall "
-                      f"({r['generated'] / r['wall_s']:.2f} generated tok/s)",
-            "host_cpus": os.cpu_count()}
+                      f"({r['generated'] / r['wall_s']:.2f} generated tok/s)"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -276,13 +328,16 @@ def main():
             result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
         result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x14 graph-replayed launches over rotating layers"
         result["decode_kv_rows_per_step"] = kv_rows
+    gpu_c1 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        gpu_c1 = config1_on_gpu(llm)
     if world > 1:
         torch.distributed.barrier()
     llm.shutdown()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del llm, eng
         torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(prompts, max_tokens, args.cpu_requests, args.cpu_new_tokens)
+        result["cpu_baseline"] = cpu_baseline(prompts, max_tokens, args.cpu_requests, args.cpu_new_tokens, gpu_c1)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

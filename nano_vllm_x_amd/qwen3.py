@@ -292,6 +292,39 @@ class Qwen3Model(nn.Module):
         return hidden_states, None
 
 
+def random_checkpoint(cfg: Qwen3Config, seed: int = 0):
+    """(name, fp32 tensor) pairs of a seeded random Qwen3 checkpoint under the Hugging Face tensor names, full
+    (unsharded) sizes, one tensor at a time.  Model.init_random loads exactly this stream, so anything else
+    that consumes it (a CPU restatement of the model in the tests) holds the same weights."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+
+    def full(rows, cols, std):
+        return torch.randn(rows, cols, generator=gen) * std
+
+    def vec(n):
+        return 1.0 + 0.1 * torch.randn(n, generator=gen)
+
+    h, d = cfg.hidden_size, cfg.head_dim
+    hq, hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    yield "model.embed_tokens.weight", full(cfg.vocab_size, h, 0.05)
+    yield "model.norm.weight", vec(h)
+    if not cfg.tie_word_embeddings:
+        yield "lm_head.weight", full(cfg.vocab_size, h, h ** -0.5)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        yield p + "self_attn.q_proj.weight", full(hq * d, h, h ** -0.5)
+        yield p + "self_attn.k_proj.weight", full(hkv * d, h, h ** -0.5)
+        yield p + "self_attn.v_proj.weight", full(hkv * d, h, h ** -0.5)
+        yield p + "self_attn.o_proj.weight", full(h, hq * d, (hq * d) ** -0.5)
+        yield p + "self_attn.q_norm.weight", vec(d)
+        yield p + "self_attn.k_norm.weight", vec(d)
+        yield p + "mlp.gate_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)
+        yield p + "mlp.up_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)
+        yield p + "mlp.down_proj.weight", full(h, cfg.intermediate_size, cfg.intermediate_size ** -0.5)
+        yield p + "input_layernorm.weight", vec(h)
+        yield p + "post_attention_layernorm.weight", vec(h)
+
+
 class Qwen3ForCausalLM(nn.Module):
     # (fused parameter, checkpoint name, shard id) -- qwen3.py:312-319
     STACKED = [("qkv_proj", "q_proj", "q"), ("qkv_proj", "k_proj", "k"), ("qkv_proj", "v_proj", "v"),
@@ -329,33 +362,7 @@ class Qwen3ForCausalLM(nn.Module):
         """Seeded random weights of the right shapes (no checkpoint exists offline).  Each full matrix
         is drawn from the same stream on every rank and then sharded, so TP=N computes the same
         function as TP=1."""
-        cfg = self.config
-        gen = torch.Generator(device="cpu").manual_seed(seed)
-
-        def full(rows, cols, std):
-            return (torch.randn(rows, cols, generator=gen) * std)
-
-        def vec(n):
-            return 1.0 + 0.1 * torch.randn(n, generator=gen)
-
-        h, d = cfg.hidden_size, cfg.head_dim
-        weights = [("model.embed_tokens.weight", full(cfg.vocab_size, h, 0.05)), ("model.norm.weight", vec(h))]
-        if not cfg.tie_word_embeddings:
-            weights.append(("lm_head.weight", full(cfg.vocab_size, h, h ** -0.5)))
-        self.load_weights(weights)
-        for i in range(cfg.num_hidden_layers):
-            p = f"model.layers.{i}."
-            self.load_weights([
-                (p + "self_attn.q_proj.weight", full(cfg.num_attention_heads * d, h, h ** -0.5)),
-                (p + "self_attn.k_proj.weight", full(cfg.num_key_value_heads * d, h, h ** -0.5)),
-                (p + "self_attn.v_proj.weight", full(cfg.num_key_value_heads * d, h, h ** -0.5)),
-                (p + "self_attn.o_proj.weight", full(h, cfg.num_attention_heads * d, (cfg.num_attention_heads * d) ** -0.5)),
-                (p + "self_attn.q_norm.weight", vec(d)), (p + "self_attn.k_norm.weight", vec(d)),
-                (p + "mlp.gate_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)),
-                (p + "mlp.up_proj.weight", full(cfg.intermediate_size, h, h ** -0.5)),
-                (p + "mlp.down_proj.weight", full(h, cfg.intermediate_size, cfg.intermediate_size ** -0.5)),
-                (p + "input_layernorm.weight", vec(h)), (p + "post_attention_layernorm.weight", vec(h)),
-            ])
+        self.load_weights(random_checkpoint(self.config, seed))
 
     @torch.no_grad()
     def load_weights(self, weights: Iterable):

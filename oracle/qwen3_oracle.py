@@ -138,3 +138,53 @@ def cpu_engine_run_oracle(cfg, prompts, max_tokens, kv_slots, max_bs, context_le
                 log(steps, b.mode, len(b.seqs))
     return {"wall_s": time.perf_counter() - t0, "steps": steps, "generated": generated,
             "nominal_tokens": int(sum(max_tokens))}
+
+
+def cpu_engine_greedy_oracle(cfg, state_dict, prompts, max_new_tokens, kv_slots, max_bs, context_len, dtype=torch.float32,
+                             keep_logits=True, forced=None):
+    """The serving loop on CPU with arg-max sampling (what temperature -> 0 or top_k = 1 gives): oracle
+    scheduler + oracle model over the weights of `state_dict` (Hugging Face names, as checkpoints and
+    nano_vllm_x_amd.qwen3.random_checkpoint give them), cast to `dtype`.
+
+    Returns dict(streams {request index: [token ids]}, logits {request index: [fp32 (vocab) row per step]} when
+    keep_logits, wall_s, prefill_s, decode_s, steps, generated, prompt_tokens).  `forced` (optional,
+    {request index: [ids]}): tokens fed instead of the arg-max ones (teacher forcing), so that the logits of two
+    implementations can be compared step by step on identical histories."""
+    from .sched_oracle import PREFILL, EngineOracle, SamplingOracle
+
+    w = pack_weights_oracle({k: v.to(dtype) for k, v in state_dict.items()}, cfg["num_hidden_layers"])
+    eng = EngineOracle(kv_slots, max_bs, context_len)
+    for i, (p, n) in enumerate(zip(prompts, max_new_tokens)):
+        eng.add(str(i), p, SamplingOracle(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=n))
+    nl, hkv, d = cfg["num_hidden_layers"], cfg["num_key_value_heads"], cfg["head_dim"]
+    k_cache = torch.zeros(nl, kv_slots, hkv, d, dtype=dtype)
+    v_cache = torch.zeros_like(k_cache)
+    rope = rope_table_oracle(d, cfg["max_position_embeddings"], cfg["rope_theta"])
+    streams = {i: [] for i in range(len(prompts))}
+    logits = {i: [] for i in range(len(prompts))}
+    t0 = time.perf_counter()
+    steps = generated = 0
+    split = {"prefill_s": 0.0, "decode_s": 0.0}
+    with torch.inference_mode():
+        while eng.sched.busy():
+            ts = time.perf_counter()
+            b = eng.sched.schedule()
+            rows = [(len(s.token_ids), s.kv_indices, s.cached_kv_len) for s in b.seqs]
+            table = block_table_oracle(rows)
+            ids = [t for s in b.seqs for t in s.token_ids[s.cached_kv_len:]]
+            pos = [p for s in b.seqs for p in range(s.cached_kv_len, len(s.token_ids))]
+            hid = qwen3_forward_oracle(w, cfg, ids, pos, k_cache, v_cache, table, rope)
+            lg = logits_oracle(w, hid[last_rows_oracle(table)]).float()
+            toks = lg.argmax(dim=-1).tolist()
+            for j, s in enumerate(b.seqs):
+                i = int(s.seq_id)
+                if forced is not None:
+                    toks[j] = forced[i][len(streams[i])]
+                streams[i].append(toks[j])
+                if keep_logits:
+                    logits[i].append(lg[j].clone())
+            generated += len(eng.absorb(b, toks))
+            steps += 1
+            split["prefill_s" if b.mode == PREFILL else "decode_s"] += time.perf_counter() - ts
+    return {"streams": streams, "logits": logits if keep_logits else None, "wall_s": time.perf_counter() - t0,
+            "steps": steps, "generated": generated, "prompt_tokens": int(sum(len(p) for p in prompts)), **split}

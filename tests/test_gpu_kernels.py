@@ -199,7 +199,12 @@ def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
     return ws
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2), (8, 4), (4, 2), (2, 1)])
+# (16, 8) Qwen3-0.6B; (32, 8) Qwen3-8B on one rank; (4, 1) Qwen3-8B over 8 ranks; (16, 2) Qwen3-32B over 4 ranks; (64, 8)
+# Qwen3-32B on one rank; the rest: Qwen3-0.6B over 2, 4, 8 ranks and other ratios
+HEAD_SHAPES = [(16, 8), (32, 8), (16, 2), (64, 8), (4, 1), (8, 2), (8, 1), (2, 2), (8, 4), (4, 2), (2, 1)]
+
+
+@pytest.mark.parametrize("hq,hkv", HEAD_SHAPES)
 def test_decode_attention_small(ops, hq, hkv):
     _decode_case(ops, 10 + hq, [1, 2, 31, 32, 33, 127, 128, 129, 300], hq, hkv)
 
@@ -269,7 +274,7 @@ def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
     assert not (d > tol).any(), f"prefill vs per-row decode: max diff {d.max():.3e}"
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 1), (8, 2), (8, 1), (2, 2), (8, 4), (4, 2), (2, 1)])
+@pytest.mark.parametrize("hq,hkv", HEAD_SHAPES)
 def test_prefill_attention_small(ops, hq, hkv):
     q_lens = [1, 5, 31, 32, 33, 64, 65, 130, 200]
     _prefill_case(ops, 30 + hq, q_lens, q_lens, hq, hkv)
@@ -512,7 +517,7 @@ def test_linear_decode_rejects_bad_shapes(ops):
 
 
 # -----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (2, 1), (8, 2), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (16, 2), (2, 1), (8, 2), (8, 1)])
 def test_decode_attention_from_raw_qkv_matches_the_two_kernel_path(ops, hq, hkv):
     """nvx_paged_decode_qkv == nvx_qknorm_rope_store followed by nvx_paged_decode: the pool rows it
     writes are bit-identical, the attention output agrees to the decode tolerance (the new token joins

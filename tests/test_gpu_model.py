@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from helpers import from_bits, golden_json, golden_npz
+from model_checks import check_close, check_logits
 
 pytestmark = pytest.mark.gpu
 
@@ -41,19 +42,15 @@ def _run_fixture(runner, meta):
 
 
 def test_tiny_qwen3_logits_match_reference_eager_and_graph():
-    """Reference logits come from bf16 GEMMs on the CPU; here hipBLASLt accumulates in another order,
-    so agreement is to bf16 working precision: |diff| <= 2^-6 * max|logit| (observed much smaller)."""
+    """Reference logits come from bf16 GEMMs on the CPU; here hipBLASLt accumulates in another order, so
+    agreement is to bf16 working precision: the bound is twice the error observed on MI355X (model_checks)."""
     g = golden_npz("g7_tiny_qwen3.npz")
     r_eager, meta = _tiny_runner(enforce_eager=True)
     got_eager = _run_fixture(r_eager, meta)
     for step in range(3):
-        want = g[f"logits{step}"]
-        tol = 2.0 ** -6 * np.abs(want).max()
-        assert np.abs(got_eager[step] - want).max() <= tol, (step, np.abs(got_eager[step] - want).max(), tol)
-        assert (np.argmax(got_eager[step], -1) == np.argmax(want, -1)).all()
-    # K rows written by the fused norm+rotary+scatter kernel vs the reference's cache (<= 2 bf16 ulp apart)
-    kc = r_eager.kv_cache.k_cache.float().cpu()
-    assert (kc - from_bits(g["k_cache"]).float()).abs().max() <= 2.0 ** -6 * kc.abs().max()
+        check_logits("g7_reference_vs_hip_eager", got_eager[step], g[f"logits{step}"], f"step {step}")
+    # K rows written by the fused norm+rotary+scatter kernel vs the reference's cache
+    check_close("g7_k_cache_vs_reference", r_eager.kv_cache.k_cache.float().cpu().numpy(), from_bits(g["k_cache"]).float().numpy())
     r_graph, meta = _tiny_runner(enforce_eager=False)
     got_graph = _run_fixture(r_graph, meta)
     assert r_graph.stats["graph_steps"] == 2
@@ -64,7 +61,8 @@ def test_tiny_qwen3_logits_match_reference_eager_and_graph():
     r_eager.kv_cache.k_cache.zero_(); r_eager.kv_cache.v_cache.zero_()
     got_unfused = _run_fixture(r_eager, meta)
     for step in range(3):
-        assert np.abs(got_unfused[step] - got_eager[step]).max() <= 2.0 ** -7 * np.abs(got_eager[step]).max()
+        check_logits("g7_unfused_vs_fused", got_unfused[step], got_eager[step], f"step {step}")
+        check_logits("g7_reference_vs_hip_unfused", got_unfused[step], g[f"logits{step}"], f"step {step}")
 
 
 def test_engine_greedy_streams_identical_eager_vs_graph():
@@ -242,7 +240,7 @@ def test_decode_projections_fused_path_matches_library_gemm_path():
     cfg = qwen3.Qwen3Config(vocab_size=1024, hidden_size=512, intermediate_size=1536, num_hidden_layers=3,
                             num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=256,
                             tie_word_embeddings=False)
-    calls = _fused_vs_library(cfg)
+    calls = _fused_vs_library(cfg, "hidden512")
     assert calls == 3 * 3 * 4, calls        # 3 decode steps x 3 layers x (qkv, o, gate_up, down)
 
 
@@ -257,10 +255,10 @@ def test_shapes_of_one_tensor_parallel_rank_of_qwen3_0_6b(tp):
     cfg = qwen3.Qwen3Config(vocab_size=2048, hidden_size=1024, intermediate_size=3072 // tp, num_hidden_layers=2,
                             num_attention_heads=16 // tp, num_key_value_heads=8 // tp, head_dim=128,
                             max_position_embeddings=256, tie_word_embeddings=False)
-    assert _fused_vs_library(cfg) > 0
+    assert _fused_vs_library(cfg, f"0.6B/tp{tp}") > 0
 
 
-def _fused_vs_library(cfg) -> int:
+def _fused_vs_library(cfg, tag: str) -> int:
     from nano_vllm_x_amd import qwen3
     from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, Sequence
     from nano_vllm_x_amd.core.model_runner import ModelRunner
@@ -303,10 +301,7 @@ def _fused_vs_library(cfg) -> int:
             qwen3.ops.linear_decode = real
         outs[fused] = got
     for step in range(4):
-        a, b = outs[True][step], outs[False][step]
-        tol = 2.0 ** -6 * np.abs(b).max()
-        assert np.abs(a - b).max() <= tol, (step, np.abs(a - b).max(), tol)
-        assert (a.argmax(-1) == b.argmax(-1)).mean() >= 0.8
+        check_logits(f"fused_vs_library[{tag}]", outs[True][step], outs[False][step], f"step {step}")
     return calls["n"]
 
 
