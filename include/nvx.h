@@ -167,6 +167,21 @@ int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, const int64_t*
                          float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
                          float sm_scale, nvx_stream_t stream);
 
+/* nvx_paged_decode for callers that cannot allocate device memory (code under hipGraph capture that has no
+ * workspace to hand over, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same arguments and the same result, bit for bit, as nvx_decode_plan(kv_len, kv_start, NULL, ...)
+ * followed by nvx_paged_decode(...), but the plan and the split partials live in an array built into the
+ * library (12.1 MiB of device memory per GPU the library runs on, held until the process ends) instead of
+ * plan_ws / partial_ws.  Limits: batch <= nvx_paged_decode_noalloc_max_batch() (256) and
+ * nvx_decode_partial_ws_floats(batch, n_q_heads, n_kv_heads) <= 3 Mi floats (met at batch 256 by 32/8, 16/2,
+ * 8/1 query/kv heads; not by 64/8); larger calls return NVX_ENOSPACE.  Calls no allocator.  Every call on a GPU
+ * uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race. */
+int64_t nvx_paged_decode_noalloc_max_batch(void);
+int nvx_paged_decode_noalloc(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                             int64_t n_slots, const int32_t* kv_indices, const int32_t* kv_len,
+                             const int64_t* kv_start, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                             float sm_scale, nvx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Paged attention, prefill: causal, variable-length, queries right-aligned to the keys.
  * Replaces BatchPrefillWithPagedKVCacheWrapper.plan/run as called from

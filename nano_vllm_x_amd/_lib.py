@@ -43,6 +43,9 @@ SIGNATURES = {
                                       _c_vp, _c_vp, _c_i64, _c_i32, _c_i32, _c_f32, _c_vp]),
     "nvx_paged_decode": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64,
                                   _c_i32, _c_i32, _c_f32, _c_vp]),
+    "nvx_paged_decode_noalloc_max_batch": (_c_i64, []),
+    "nvx_paged_decode_noalloc": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64,
+                                          _c_i32, _c_i32, _c_f32, _c_vp]),
     "nvx_prefill_plan_ws_ints": (_c_i64, [_c_i64]),
     "nvx_prefill_plan": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp]),
     "nvx_paged_prefill": (_c_i32, [_c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,

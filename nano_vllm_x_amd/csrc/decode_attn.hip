@@ -19,6 +19,8 @@
 #include "nvx_dev.h"
 #include "rope_dev.h"
 
+#include <mutex>
+
 #define DEC_TARGET_UNITS 2048   // work units (chunk x kv head) the plan aims for
 #define DEC_MIN_CHUNK 128       // tokens
 #define DEC_MAX_CHUNK (1 << 24) // tokens: "do not split"
@@ -510,6 +512,68 @@ extern "C" int nvx_paged_decode(const void* q, int64_t q_row_stride, const void*
                                 nvx_stream_t stream) {
     return dec_launch(q, q_row_stride, k_cache, v_cache, n_slots, kv_indices, plan_ws, partial_ws, out, batch, n_q_heads,
                       n_kv_heads, sm_scale, nullptr, n_q_heads * 128, "nvx_paged_decode", stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Entry point for callers that cannot allocate: plan, attention and merge out of one file-scope device
+// array instead of caller-provided workspaces.  Each GPU the library runs on holds its own copy of the
+// array (at its own address) until the process ends; every call on a GPU uses that GPU's copy, so calls that
+// overlap on one GPU race.  Nothing in it has to start at zero: the plan kernel writes the header, every record
+// and every sequence's (first item, count) pair before the attention kernel reads them, and the merge reads
+// only partials the attention kernel of the same call wrote.
+#define NVX_NOALLOC_MAX_BATCH 256
+#define NVX_NOALLOC_PLAN_INTS 20480                  // >= nvx_decode_plan_ws_ints(256, 1) = 19016
+#define NVX_NOALLOC_PARTIAL_FLOATS (3 * 1024 * 1024)   // 12 MiB: e.g. 32 q / 8 kv heads, 16 / 2 or 8 / 1 at batch 256
+#define NVX_NOALLOC_BYTES (NVX_NOALLOC_PLAN_INTS * 4 + NVX_NOALLOC_PARTIAL_FLOATS * 4)
+static __device__ __align__(256) unsigned char scratch[NVX_NOALLOC_BYTES];
+
+#define NVX_MAX_DEVICES 64
+static std::mutex noalloc_mutex;
+static unsigned char* noalloc_ptr[NVX_MAX_DEVICES];   // per device: the address of ITS copy of `scratch`
+
+// Address of the current device's copy of the array (looked up once per device, with that device current).
+static int noalloc_scratch(unsigned char** ptr, const char* who) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return nvx_fail(NVX_ELAUNCH, "%s: hipGetDevice: %s", who, hipGetErrorString(e));
+    NVX_REQUIRE(dev >= 0 && dev < NVX_MAX_DEVICES, NVX_EUNSUPPORTED, "%s: device ordinal %d outside [0, %d)", who, dev, NVX_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(noalloc_mutex);
+    if (!noalloc_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return nvx_fail(NVX_ELAUNCH, "%s: hipGetSymbolAddress(scratch): %s", who, hipGetErrorString(e));
+        noalloc_ptr[dev] = static_cast<unsigned char*>(p);
+    }
+    *ptr = noalloc_ptr[dev];
+    return NVX_OK;
+}
+
+extern "C" int64_t nvx_paged_decode_noalloc_max_batch(void) { return NVX_NOALLOC_MAX_BATCH; }
+
+extern "C" int nvx_paged_decode_noalloc(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                                        int64_t n_slots, const int32_t* kv_indices, const int32_t* kv_len,
+                                        const int64_t* kv_start, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                                        float sm_scale, nvx_stream_t stream) {
+    const char* who = "nvx_paged_decode_noalloc";
+    NVX_REQUIRE(batch > 0 && n_q_heads > 0 && n_kv_heads > 0, NVX_EINVAL, "%s: bad size", who);
+    NVX_REQUIRE(kv_len && kv_start, NVX_EINVAL, "%s: null pointer", who);
+    NVX_REQUIRE(batch <= NVX_NOALLOC_MAX_BATCH, NVX_ENOSPACE, "%s: batch %lld exceeds the built-in scratch (at most %d sequences)", who,
+                (long long)batch, NVX_NOALLOC_MAX_BATCH);
+    const int64_t plan_ints = nvx_decode_plan_ws_ints(batch, n_kv_heads);
+    const int64_t part_floats = nvx_decode_partial_ws_floats(batch, n_q_heads, n_kv_heads);
+    NVX_REQUIRE(plan_ints <= NVX_NOALLOC_PLAN_INTS && part_floats <= NVX_NOALLOC_PARTIAL_FLOATS, NVX_ENOSPACE,
+                "%s: batch %lld with %d query / %d kv heads needs %lld plan ints and %lld partial floats; the built-in scratch "
+                "holds %d and %d", who, (long long)batch, n_q_heads, n_kv_heads, (long long)plan_ints, (long long)part_floats,
+                NVX_NOALLOC_PLAN_INTS, NVX_NOALLOC_PARTIAL_FLOATS);
+    unsigned char* ptr = nullptr;
+    int rc = noalloc_scratch(&ptr, who);
+    if (rc) return rc;
+    int32_t* plan_ws = reinterpret_cast<int32_t*>(ptr);
+    float* partial_ws = reinterpret_cast<float*>(ptr + (size_t)NVX_NOALLOC_PLAN_INTS * 4);
+    rc = nvx_decode_plan(kv_len, kv_start, nullptr, batch, n_kv_heads, plan_ws, NVX_NOALLOC_PLAN_INTS, stream);
+    if (rc) return rc;
+    return dec_launch(q, q_row_stride, k_cache, v_cache, n_slots, kv_indices, plan_ws, partial_ws, out, batch, n_q_heads,
+                      n_kv_heads, sm_scale, nullptr, n_q_heads * 128, who, stream);
 }
 
 extern "C" int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
