@@ -303,6 +303,18 @@ def main():
         wall = float(w.item())
     stats1 = eng.model_runner.stats
     nominal = sum(max_tokens) * args.steps
+    # what ran, not what was asked for: a decode graph that could not be captured (a collective RCCL refuses to
+    # capture) leaves the runner on eager decode steps, and the line must say so
+    runner = eng.model_runner
+    graph_steps = stats1["graph_steps"] - stats0.get("graph_steps", 0)
+    eager_steps = stats1["eager_decode_steps"] - stats0.get("eager_decode_steps", 0)
+    if runner.graph is not None and graph_steps > 0 and eager_steps == 0:
+        decode_mode = "hipGraph"
+    elif graph_steps == 0:
+        decode_mode = "eager" + (f" (hipGraph capture failed: {runner.graph_capture_error})" if runner.graph_capture_error else "")
+    else:
+        decode_mode = f"mixed: {graph_steps} hipGraph steps, {eager_steps} eager steps"
+    graph_broken = not args.enforce_eager and decode_mode != "hipGraph"
 
     result = {
         "metric": METRIC, "value": round(nominal / wall, 2), "unit": "tokens/s", "n_gpus": world,
@@ -312,7 +324,7 @@ def main():
         "config": {"workload": f"reference bench.py: {args.num_seqs} requests, prompt U[100,1024], max_tokens U[100,1024], "
                                f"temperature 0.6, ignore_eos, all submitted at once, {args.model} geometry",
                    "geometry": args.model, "ranks": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
-                   "kv_cache_slots": eng.kv_cache_size, "decode": "eager" if args.enforce_eager else "hipGraph",
+                   "kv_cache_slots": eng.kv_cache_size, "decode": decode_mode,
                    "run_ahead": eng.run_ahead, "steps_queued_ahead": eng.ahead_steps,
                    "max_prefill_tokens": args.max_prefill_tokens or None},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
@@ -340,6 +352,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline(prompts, max_tokens, args.cpu_requests, args.cpu_new_tokens, gpu_c1)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if graph_broken:
+        # hipGraph decode was asked for and is not what (all of) the timed steps ran on: the line above says what did
+        # run, and the run fails so that the number cannot pass for a hipGraph one
+        print(f"bench.py: decode ran as '{decode_mode}' although hipGraph was requested", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ What differs, by design, on MI355X:
 from __future__ import annotations
 
 import gc
+import os
 import sys
 import time
 from typing import Optional
@@ -61,6 +62,7 @@ class ModelRunner:
         self._stage_output, self._defer_stage_send = None, False
         self._last_done = 0.0
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
+        self.graph_capture_error: Optional[str] = None    # set when a tensor-parallel decode graph could not be captured
 
     # -- set-up -----------------------------------------------------------------------------------
     def load_model(self, state_dict_iter=None):
@@ -121,8 +123,9 @@ class ModelRunner:
             try:
                 self.capture_graph()
             except RuntimeError as e:
-                if self.tp_size == 1:
+                if self.tp_size == 1 or os.environ.get("NVX_REQUIRE_GRAPH") == "1":
                     raise
+                self.graph_capture_error = str(e).splitlines()[0]
                 # a collective that cannot be captured on this RCCL build: every rank hits the same error at
                 # the same point, so all fall back together to eager decode steps (same kernels, launched
                 # one by one)

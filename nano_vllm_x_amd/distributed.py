@@ -25,17 +25,31 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _PP_RANK = 0
 _PP_SIZE = 1
+_FORCED = False    # one rank, but issue every collective anyway (NVX_FORCE_COLLECTIVES=1)
 
 
 def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | None = None, port: int = 29500,
                          device_ids: list | None = None, pp_size: int = 1):
     """Join (or create) the process group.  Under torchrun the RANK/WORLD_SIZE/MASTER_* variables are
     used; a single process with tp_size 1 (and one stage) needs no group at all.  Returns the global rank."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED
     world = tp_size * pp_size
     if world <= 1:
         _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = None, 0, 1, 0, 1
+        _FORCED = os.environ.get("NVX_FORCE_COLLECTIVES") == "1"
+        if _FORCED:
+            # A one-rank RCCL group: the model then runs the code path of a tensor-parallel rank (bf16 row-parallel
+            # outputs handed to all-reduce, masked embedding, LM-head gather, id broadcast) with every collective
+            # really issued -- also inside the captured decode graph.  The only way to exercise RCCL under hipGraph
+            # capture on a box with one GPU.
+            if not dist.is_initialized():
+                dev = device_ids[0] if device_ids else 0
+                torch.cuda.set_device(dev)
+                dist.init_process_group(backend=backend or "nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                                        device_id=torch.device("cuda", dev) if (backend or "nccl") == "nccl" else None)
+            _TP_GROUP = dist.group.WORLD
         return 0
+    _FORCED = False
     if backend is None:
         # NVX_TP_BACKEND=gloo lets several ranks share one GPU (rehearsals on a one-GPU box: RCCL refuses
         # two ranks on one device); collectives then stage through the host and cannot be graph-captured
@@ -66,6 +80,12 @@ def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | N
             if stage == _PP_RANK:
                 _TP_GROUP = g
     return me
+
+
+def collectives_active() -> bool:
+    """True when row-parallel outputs must go through all-reduce (several ranks, or one rank that issues its
+    collectives anyway)."""
+    return _TP_SIZE > 1 or _FORCED
 
 
 def tp_rank() -> int:
@@ -100,7 +120,7 @@ def _via_host(x: torch.Tensor) -> bool:
 
 
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
-    if _TP_SIZE > 1:
+    if _TP_SIZE > 1 or _FORCED:
         if _via_host(x):
             h = x.float().cpu() if x.dtype == torch.bfloat16 else x.cpu()
             dist.all_reduce(h, group=_TP_GROUP)
@@ -112,7 +132,7 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
 
 def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     """Concatenate the ranks' shards along the last dimension."""
-    if _TP_SIZE == 1:
+    if _TP_SIZE == 1 and not _FORCED:
         return x
     x = x.contiguous()
     if _via_host(x):
@@ -142,7 +162,7 @@ def tp_broadcast(x: torch.Tensor, src: int = 0) -> torch.Tensor:
 def broadcast_sampled_ids(x: torch.Tensor) -> torch.Tensor:
     """The sampled ids, from TP rank 0 of the last stage to every rank of the job: each rank's scheduler
     then applies the same tokens and stays in lockstep without host-side messages."""
-    if _TP_SIZE * _PP_SIZE > 1:
+    if _TP_SIZE * _PP_SIZE > 1 or _FORCED:
         src = (_PP_SIZE - 1) * _TP_SIZE
         if _via_host(x):
             h = x.cpu()
@@ -215,7 +235,7 @@ def barrier():
 
 
 def shutdown():
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED
     if dist.is_initialized():
         dist.destroy_process_group()
-    _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE = None, 0, 1, 0, 1
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED = None, 0, 1, 0, 1, False

@@ -114,6 +114,7 @@ class PagedDecodeWrapper:
         self._kv_start = self._kv_len = self._kv_indices = None
         self._batch = 0
         self.qkv_fused = False
+        self._new_slots = None
 
     def _ensure(self, batch: int, hq: int, hkv: int, device):
         if self._ws is None or self._ws.max_batch < batch or (self._ws.n_q_heads, self._ws.n_kv_heads) != (hq, hkv):
@@ -121,6 +122,13 @@ class PagedDecodeWrapper:
             self._ws = ops.DecodeWorkspace(cap, hq, hkv, device)
             self._kv_start = torch.zeros(cap, dtype=torch.int64, device=device)
             self._kv_len = torch.zeros(cap, dtype=torch.int32, device=device)
+
+    def expect_new_rows(self, out_slots: Optional[torch.Tensor]):
+        """Tell the next plan() which slot each sequence's new K/V row goes to (int64, one per sequence; it must
+        be the last entry of the sequence's slot list).  The plan then carries them, and run_qkv() may be used:
+        norm + rotary + scatter of the new row inside the attention launch.  Kept apart from plan() because
+        plan()'s keyword set is the one the reference passes."""
+        self._new_slots = out_slots
 
     def plan(self, indptr, indices, last_page_len, num_qo_heads, num_kv_heads, head_dim, page_size=1,
              q_data_type=None, kv_data_type=None, **_):
@@ -132,7 +140,11 @@ class PagedDecodeWrapper:
         self._kv_start[:b].copy_(indptr[:-1])
         torch.sub(indptr[1:], indptr[:-1], out=self._kv_len[:b])
         self._kv_indices = indices if not self._static or self._indices_buf is None else self._indices_buf
-        ops.decode_plan(self._kv_len[:b], self._kv_start[:b], self._ws)
+        new_slots, self._new_slots = self._new_slots, None
+        if new_slots is not None and new_slots.numel() != b:
+            new_slots = None
+        ops.decode_plan(self._kv_len[:b], self._kv_start[:b], self._ws, out_slots=new_slots)
+        self.qkv_fused = new_slots is not None
 
     def bind_table(self, kv_indices, kv_start, kv_len, batch: int, ws: ops.DecodeWorkspace, qkv_fused: bool = False):
         """Use caller-owned static buffers (the device-resident block table); the plan kernel is then
@@ -274,6 +286,8 @@ class AttentionBackend:
                          head_dim_vo=self.head_dim, page_size=1, causal=True, q_data_type=self.dtype, kv_data_type=self.dtype)
         elif batch.forward_mode == ForwardMode.DECODE:
             wrapper = self.decode_wrapper
+            # the same kernels as a captured step launches: the attention launch makes and stores the new rows
+            wrapper.expect_new_rows(dev["output_kv_indices"])
             wrapper.plan(indptr=dev["paged_kv_indptr"], indices=dev["paged_kv_indices"],
                          last_page_len=dev["paged_kv_last_page_len"], num_qo_heads=self.num_qo_heads,
                          num_kv_heads=self.num_kv_heads, head_dim=self.head_dim, page_size=1, q_data_type=self.dtype,

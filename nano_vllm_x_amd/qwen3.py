@@ -97,7 +97,7 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Ten
     use = (x.is_cuda and x.dtype == torch.bfloat16 and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
            and n * k * 2 <= DECODE_LINEAR_MAX_WEIGHT_BYTES)
     if kind in ("o", "down"):
-        splits = ops.linear_decode_splits(n, k) if use and tpd.tp_size() == 1 and n % 16 == 0 else 0
+        splits = ops.linear_decode_splits(n, k) if use and not tpd.collectives_active() and n % 16 == 0 else 0
         if splits:
             return ops.linear_decode(x, weight, mode=2, k_splits=splits)
         return F.linear(x, weight)
@@ -218,7 +218,7 @@ class VocabParallelEmbedding(nn.Module):
         self.weight = nn.Parameter(torch.empty(self.per_rank, hidden))
 
     def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        if tpd.tp_size() == 1:
+        if not tpd.collectives_active():
             return F.embedding(ids, self.weight)
         local = ids - self.start
         mine = (local >= 0) & (local < self.per_rank)

@@ -24,11 +24,12 @@ MEASURED: dict = {
     "config1_cpu_fp32_engine_vs_hip_engine": 0.0177136,
     "config3_prefix_reuse_vs_recompute": 0,
     "config5_chunked_vs_one_step_prefill": 0,
+    "forced_collectives_vs_one_rank": 0.0042735,
     "fused_vs_library[0.6B/tp2]": 0.00506073,
     "fused_vs_library[0.6B/tp4]": 0.00408021,
     "fused_vs_library[0.6B/tp8]": 0,
     "fused_vs_library[config3_qwen3_8b_tp1]": 0.00865801,
-    "fused_vs_library[config4_qwen3_8b_tp8]": 0.00614754,
+    "fused_vs_library[config4_qwen3_8b_tp8]": 0.00775194,
     "fused_vs_library[config5_qwen3_32b_tp4_stage]": 0,
     "fused_vs_library[hidden512]": 0.00441505,
     "g7_k_cache_vs_reference": 0.00680272,

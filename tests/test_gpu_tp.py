@@ -191,3 +191,90 @@ def test_pipeline_engine_keeps_batches_in_flight_and_ranks_agree():
     # both stages worked on most ticks: batches really overlapped (one batch at a time would give 50 %)
     for st in (stats0, stats1):
         assert st["stage_busy_ticks"] >= 0.75 * st["ticks"], st
+
+
+# -- RCCL inside the captured decode graph, on the one GPU of the test box -------------------------------
+def _run_forced(rank, port, q, eager):
+    """One rank with NVX_FORCE_COLLECTIVES=1: a one-rank RCCL group, the tensor-parallel code path (bf16
+    row-parallel outputs through all-reduce, masked embedding, LM-head gather, id broadcast)."""
+    try:
+        os.environ["NVX_FORCE_COLLECTIVES"] = "1"
+        import torch.distributed as dist
+
+        from nano_vllm_x_amd import distributed as tpd
+        from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, SamplingParams, Sequence
+        from nano_vllm_x_amd.core.model_runner import ModelRunner
+        from nano_vllm_x_amd.qwen3 import Qwen3Config
+
+        counts = {"all_reduce": 0, "all_gather": 0, "capturing": 0}
+        real_ar, real_ag = dist.all_reduce, dist.all_gather_into_tensor
+
+        def ar(t, *a, **k):
+            counts["all_reduce"] += 1
+            counts["capturing"] += bool(t.is_cuda and torch.cuda.is_current_stream_capturing())
+            return real_ar(t, *a, **k)
+
+        def ag(o, t, *a, **k):
+            counts["all_gather"] += 1
+            return real_ag(o, t, *a, **k)
+
+        dist.all_reduce, dist.all_gather_into_tensor = ar, ag
+        r = ModelRunner(model="forced", max_bs=8, tp_size=1, nccl_port=port, enforce_eager=eager, context_len=128,
+                        config=Qwen3Config.from_dict(CFG), seed=5)
+        assert tpd.collectives_active() and dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        r.load_model()
+        r.initialize_kv_cache(512)     # captures the decode graphs unless eager
+        captured = counts["capturing"]
+        rng = np.random.default_rng(9)
+        seqs, slot = [], 0
+        for i, n in enumerate(PROMPT_LENS):
+            p = rng.integers(0, CFG["vocab_size"], size=n).tolist()
+            seqs.append(Sequence(seq_id=f"s{i}", token_ids=p, num_tokens=n, prompt_len=n, kv_indices=list(range(slot, slot + n)),
+                                 sampling_params=SamplingParams(temperature=1.0, top_k=1, ignore_eos=True, max_new_tokens=8)))
+            slot += n + 8
+        logits = []
+        for step in range(3):
+            mode = ForwardMode.PREFILL if step == 0 else ForwardMode.DECODE
+            lg = r.compute_logits(ForwardBatch(forward_mode=mode, num_seqs=len(seqs), seqs=seqs))
+            logits.append(lg.float().cpu().numpy())
+            for s in seqs:
+                s.cached_kv_len = len(s.kv_indices)
+                s.token_ids.append(int(rng.integers(0, CFG["vocab_size"])))
+                s.kv_indices.append(s.kv_indices[-1] + 1)
+        stats = dict(r.stats)
+        r.shutdown()
+        q.put((eager, (logits, stats, dict(counts), captured), None))
+    except Exception:   # noqa: BLE001
+        q.put((eager, None, traceback.format_exc()))
+
+
+def test_rccl_collectives_are_captured_in_the_decode_graph_on_one_rank():
+    """The decode hipGraph of a tensor-parallel rank holds RCCL all-reduces (two per layer).  With one GPU the
+    only RCCL group that can exist has one rank; NVX_FORCE_COLLECTIVES=1 makes the model issue every collective
+    on it.  Capture must succeed with all-reduce calls made while the stream is capturing, the replayed graph
+    must give the eager steps' logits bit for bit, and both must agree with the ordinary one-rank model (which
+    sums its row-parallel projections in fp32 inside the next norm instead of rounding them to bf16 first)."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for eager in (False, True):        # one after the other: each is a process with its own one-rank group
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        q = ctx.Queue()
+        p = ctx.Process(target=_run_forced, args=(0, port, q, eager))
+        p.start()
+        key, res, err = q.get(timeout=240)
+        p.join(timeout=60)
+        assert err is None, f"forced-collectives run (eager={eager}) failed:\n{err}"
+        out[key] = res
+    g_logits, g_stats, g_counts, g_captured = out[False]
+    e_logits, e_stats, e_counts, _ = out[True]
+    layers = CFG["num_hidden_layers"]
+    assert g_captured >= 2 * layers, f"only {g_captured} all-reduce calls were made under stream capture"
+    assert g_stats["graph_steps"] == 2 and g_stats["eager_decode_steps"] == 0 and e_stats["graph_steps"] == 0
+    assert e_counts["all_reduce"] >= 3 * (2 * layers + 1) and e_counts["all_gather"] >= 3
+    for step in range(3):
+        assert np.array_equal(g_logits[step], e_logits[step]), f"step {step}: graph replay differs from eager launches"
+    want, _, _ = _run_model(1, 0, 0)
+    for step in range(3):
+        check_logits("forced_collectives_vs_one_rank", g_logits[step], want[step], f"step {step}")
