@@ -191,16 +191,18 @@ def cmd_sampler(args):
             ops.sample(logits, t, k, p, mp, 1, n[0], out=out)
 
         dt = timed(run, args.reps)
-        k2 = torch.full((b,), 50, dtype=torch.int64, device=DEV)
-        p2 = torch.full((b,), 0.9, device=DEV)
+        res = {"kernel": "sample", "B": b, "plain_us": round(dt * 1e6, 1), "GBps": round(b * v * 2 / dt / 1e9, 1)}
+        for name, kk, pp, mm in (("topk50_topp0.9", 50, 0.9, 0.0), ("topp0.9", v, 0.9, 0.0), ("topk50", 50, 1.0, 0.0), ("minp0.05", v, 1.0, 0.05)):
+            k2 = torch.full((b,), kk, dtype=torch.int64, device=DEV)
+            p2 = torch.full((b,), pp, device=DEV)
+            m2 = torch.full((b,), mm, device=DEV)
 
-        def run2():
-            n[0] += 1
-            ops.sample(logits, t, k2, p2, mp, 1, n[0], out=out)
+            def run2():
+                n[0] += 1
+                ops.sample(logits, t, k2, p2, m2, 1, n[0], out=out)
 
-        dt2 = timed(run2, max(2, args.reps // 4))
-        print(json.dumps({"kernel": "sample", "B": b, "plain_us": round(dt * 1e6, 1), "GBps": round(b * v * 2 / dt / 1e9, 1),
-                          "topk_topp_us": round(dt2 * 1e6, 1)}))
+            res[name + "_us"] = round(timed(run2, max(2, args.reps // 4)) * 1e6, 1)
+        print(json.dumps(res))
 
 
 def cmd_linear(args):
