@@ -326,9 +326,9 @@ class ModelRunner:
     def _decode_forward(self, bs: int) -> torch.Tensor:
         """The body of a captured decode step for a padded batch of `bs` rows."""
         bt = self.block_table
-        ops.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
-                              bt.positions, bt.input_ids, prev_ids=self._sample_out)
-        ops.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], self.decode_ws, out_slots=bt.out_slots[:bs])
+        torch.ops.nvx.decode_step_setup(bt.step_dev, bt.max_bs, bs, bt.table, bt.pad_start, bt.kv_start, bt.kv_len, bt.out_slots,
+                                        bt.positions, bt.input_ids, self._sample_out)
+        torch.ops.nvx.decode_plan(bt.kv_len[:bs], bt.kv_start[:bs], bt.out_slots[:bs], self.num_kv_heads, self.decode_ws.plan)
         wrapper = self._graph_wrappers[bs]
         md = AttentionMetadata(forward_mode=ForwardMode.DECODE, kv_cache=self.kv_cache, output_kv_indices=bt.out_slots[:bs],
                                wrapper=wrapper)

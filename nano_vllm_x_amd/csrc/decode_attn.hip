@@ -230,7 +230,7 @@ __device__ __forceinline__ nvx_u32x4 dec_new_key(const uint16_t* row, int hq_tot
 //   the new key, writes the new k/v row into the pool and attends to it from registers (the row is the
 //   last entry of the sequence's slot list and is skipped when reading the pool).
 template <int G, int TPQ, bool QKV>
-__global__ __launch_bounds__(256, (G <= 2 ? 4 : 2)) void paged_decode_kernel(
+__global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) ? 4 : 2)) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ plan, float* __restrict__ partial, uint16_t* __restrict__ out, int hkv,

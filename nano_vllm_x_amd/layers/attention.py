@@ -25,6 +25,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from .. import torch_ops  # noqa: F401  (registers torch.ops.nvx.*, which the wrappers below launch through)
 from ..core.common import ForwardBatch, ForwardMode
 from ..core.kv_cache import KVCachePool
 
@@ -82,7 +83,7 @@ class PagedPrefillWrapper:
         b = qo_indptr.numel() - 1
         if self._plan_ws is None or self._plan_ws.numel() < 3 * (b + 2):
             self._plan_ws = ops.prefill_plan_ws(max(b, 256), qo_indptr.device)
-        ops.prefill_plan(qo_indptr, self._plan_ws)
+        torch.ops.nvx.prefill_plan(qo_indptr, self._plan_ws)
         self._planned = (qo_indptr, paged_kv_indptr, paged_kv_indices, num_qo_heads, num_kv_heads)
 
     def run(self, q, paged_kv_cache, out=None):
@@ -90,8 +91,12 @@ class PagedPrefillWrapper:
         k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)
         t = q.shape[0]
         scale = self._sm_scale if self._sm_scale is not None else 128 ** -0.5
-        o = ops.paged_prefill(q.reshape(t, hq * 128), k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, self._plan_ws,
-                              hq, hkv, scale, out=out)
+        if out is None:
+            o = torch.ops.nvx.paged_prefill(q.reshape(t, hq * 128), k_cache, v_cache, qo_indptr, kv_indptr, kv_indices,
+                                            self._plan_ws, hq, hkv, scale)
+        else:   # a caller-provided output buffer: the operator form allocates its result
+            o = ops.paged_prefill(q.reshape(t, hq * 128), k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, self._plan_ws,
+                                  hq, hkv, scale, out=out)
         return o.view(t, hq, 128)
 
 
@@ -143,7 +148,7 @@ class PagedDecodeWrapper:
         new_slots, self._new_slots = self._new_slots, None
         if new_slots is not None and new_slots.numel() != b:
             new_slots = None
-        ops.decode_plan(self._kv_len[:b], self._kv_start[:b], self._ws, out_slots=new_slots)
+        torch.ops.nvx.decode_plan(self._kv_len[:b], self._kv_start[:b], new_slots, num_kv_heads, self._ws.plan)
         self.qkv_fused = new_slots is not None
 
     def bind_table(self, kv_indices, kv_start, kv_len, batch: int, ws: ops.DecodeWorkspace, qkv_fused: bool = False):
@@ -157,15 +162,25 @@ class PagedDecodeWrapper:
         """Attention straight from the raw fused projection (see ops.paged_decode_qkv): replaces the
         q/k norm + rotary + scatter launch and run()."""
         k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)
+        scale = self._sm_scale if self._sm_scale is not None else 128 ** -0.5
+        if out is None and qkv.shape[0] == self._batch:
+            ws = self._ws
+            return torch.ops.nvx.paged_decode_qkv(qkv, positions, cos_sin_cache, q_weight, k_weight, eps, k_cache, v_cache,
+                                                  self._kv_indices, ws.plan, ws.partial, ws.n_q_heads, ws.n_kv_heads, scale)
         return ops.paged_decode_qkv(qkv, positions, cos_sin_cache, q_weight, k_weight, eps, k_cache, v_cache, self._kv_indices,
-                                    self._batch, self._ws, self._sm_scale if self._sm_scale is not None else 128 ** -0.5, out=out)
+                                    self._batch, self._ws, scale, out=out)
 
     def run(self, q, paged_kv_cache, out=None):
         k_cache, v_cache = (_as_nhd(c) for c in paged_kv_cache)
         b = self._batch
-        hq = self._ws.n_q_heads
-        o = ops.paged_decode(q.reshape(b, hq * 128), k_cache, v_cache, self._kv_indices, b, self._ws,
-                             self._sm_scale if self._sm_scale is not None else 128 ** -0.5, out=out)
+        ws = self._ws
+        hq = ws.n_q_heads
+        scale = self._sm_scale if self._sm_scale is not None else 128 ** -0.5
+        if out is None:
+            o = torch.ops.nvx.paged_decode(q.reshape(b, hq * 128), k_cache, v_cache, self._kv_indices, ws.plan, ws.partial, hq,
+                                           ws.n_kv_heads, scale)
+        else:
+            o = ops.paged_decode(q.reshape(b, hq * 128), k_cache, v_cache, self._kv_indices, b, ws, scale, out=out)
         return o.view(b, hq, 128)
 
 

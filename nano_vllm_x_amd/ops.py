@@ -196,12 +196,30 @@ class DecodeWorkspace:
         self.partial = torch.empty(lib.nvx_decode_partial_ws_floats(max_batch, n_q_heads, n_kv_heads), dtype=torch.float32,
                                    device=device)
 
+    @classmethod
+    def from_tensors(cls, plan: torch.Tensor, partial, n_q_heads: int, n_kv_heads: int) -> "DecodeWorkspace":
+        """A workspace over tensors the caller already holds (how the custom ops receive it).  The batch it can
+        serve is what both tensors have room for, by the library's own sizing rules."""
+        lib = _lib.load()
+        _need(plan.dtype == torch.int32 and plan.is_contiguous(), "decode workspace: plan must be contiguous int32")
+        self = cls.__new__(cls)
+        self.n_q_heads, self.n_kv_heads, self.plan, self.partial = n_q_heads, n_kv_heads, plan, partial
+        # nvx_decode_plan_ws_ints(b, hkv) = 8 + 8 * (b + 2048 / hkv + 8) + 2 * b, nvx_decode_partial_ws_floats likewise linear in b
+        fixed = int(lib.nvx_decode_plan_ws_ints(0, n_kv_heads))
+        mb = (plan.numel() - fixed) // 10
+        if partial is not None:
+            _need(partial.dtype == torch.float32 and partial.is_contiguous(), "decode workspace: partials must be contiguous fp32")
+            per = int(lib.nvx_decode_partial_ws_floats(1, n_q_heads, n_kv_heads)) - int(lib.nvx_decode_partial_ws_floats(0, n_q_heads, n_kv_heads))
+            mb = min(mb, (partial.numel() - int(lib.nvx_decode_partial_ws_floats(0, n_q_heads, n_kv_heads))) // max(1, per))
+        self.max_batch = max(0, int(mb))
+        return self
+
 
 def decode_plan(kv_len, kv_start, ws: DecodeWorkspace, out_slots=None):
     """Cut the batch's sequences into chunks (device side); must precede paged_decode of the same step.
     `out_slots` (int64 per sequence, -1 = none) is needed by paged_decode_qkv: the slot the step's new
     K/V row goes to."""
-    _dev(kv_len, kv_start, out_slots)
+    _dev(kv_len, kv_start, out_slots, ws.plan)
     b = kv_len.numel()
     if out_slots is not None:
         _need(out_slots.dtype == torch.int64 and out_slots.is_contiguous() and out_slots.numel() == b, "decode_plan: out_slots")
@@ -261,6 +279,27 @@ def paged_decode(q, k_cache, v_cache, kv_indices, batch: int, ws: DecodeWorkspac
     _lib.check(lib.nvx_paged_decode(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
                                     _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv, float(sm_scale), _stream()),
                "nvx_paged_decode")
+    return out
+
+
+def paged_decode_noalloc(q, k_cache, v_cache, kv_indices, kv_len, kv_start, n_q_heads: int, n_kv_heads: int, sm_scale, out=None):
+    """decode_plan + paged_decode without a workspace: plan and partials live in an array built into the library
+    (one per GPU; batch <= 256; calls that overlap on one GPU race).  For callers that cannot allocate."""
+    _dev(q, k_cache, v_cache, kv_indices, kv_len, kv_start)
+    b = kv_len.numel()
+    q2 = q.view(b, n_q_heads * 128)
+    _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_decode_noalloc: q layout")
+    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+          tuple(k_cache.shape[-2:]) == (n_kv_heads, 128) and v_cache.shape == k_cache.shape, "paged_decode_noalloc: cache layout")
+    _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode_noalloc: kv_indices must be int32")
+    _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and kv_start.dtype == torch.int64 and kv_start.is_contiguous()
+          and kv_start.numel() == b, "paged_decode_noalloc: kv_len int32 / kv_start int64, one per sequence")
+    if out is None:
+        out = torch.empty((b, n_q_heads * 128), dtype=BF16, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.nvx_paged_decode_noalloc(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
+                                            _ptr(kv_len), _ptr(kv_start), _ptr(out), b, n_q_heads, n_kv_heads, float(sm_scale),
+                                            _stream()), "nvx_paged_decode_noalloc")
     return out
 
 

@@ -1,23 +1,58 @@
 """`torch.ops.nvx.*`: the C-ABI kernels as PyTorch custom ops (device key only, no CPU kernels).
 
-Importing this module registers the ops.  They call the same wrappers as `nano_vllm_x_amd.ops`; the
-engine itself calls those wrappers directly (a dispatcher hop per launch buys nothing inside a
-captured graph), so this module is for callers that want operator objects: module graphs written
-against `torch.ops`, `torch.library.opcheck`, export.
+Importing this module registers the ops.  Every op is a thin call into `nano_vllm_x_amd.ops` (argument checks,
+output allocation, one launch through the C ABI on the current stream).  The paged-attention wrappers of
+`layers/attention.py` -- the objects that stand where the reference's third-party attention wrappers stood
+(nanovllmx/layers/attention.py:360-369) -- launch their kernels through these operators, so the attention path of
+the engine is "custom ops over a C ABI" end to end; workspaces are ordinary tensors passed in and mutated.
 """
 from __future__ import annotations
+
+from typing import Optional
 
 import torch
 
 from . import ops
 
 _LIB = torch.library.Library("nvx", "DEF")
-_LIB.define("store_kvcache(Tensor k, Tensor v, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor kv_indices) -> ()")
-_LIB.define("rmsnorm(Tensor x, Tensor weight, float eps) -> Tensor")
-_LIB.define("rmsnorm_residual(Tensor x, Tensor residual, Tensor weight, float eps) -> (Tensor, Tensor)")
-_LIB.define("rope(Tensor positions, Tensor q, Tensor k, Tensor cos_sin) -> (Tensor, Tensor)")
-_LIB.define("silu_mul(Tensor x) -> Tensor")
-_LIB.define("sample(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps, int seed, int offset) -> Tensor")
+_DEFS = {
+    "store_kvcache": "(Tensor k, Tensor v, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor kv_indices) -> ()",
+    "rmsnorm": "(Tensor x, Tensor weight, float eps) -> Tensor",
+    "rmsnorm_residual": "(Tensor x, Tensor residual, Tensor weight, float eps) -> (Tensor, Tensor)",
+    "rope": "(Tensor positions, Tensor q, Tensor k, Tensor cos_sin) -> (Tensor, Tensor)",
+    "silu_mul": "(Tensor x) -> Tensor",
+    "sample": "(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps, int seed, int offset) -> Tensor",
+    "sampler_probs": "(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps) -> Tensor",
+    "qknorm_rope_store": "(Tensor qkv, Tensor positions, Tensor cos_sin, Tensor q_weight, Tensor k_weight, float eps, Tensor slots, "
+                         "Tensor(a!) k_cache, Tensor(b!) v_cache, int n_q_heads, int n_kv_heads) -> Tensor",
+    # paged attention, decode: plan once per step, then one call per layer
+    "decode_plan": "(Tensor kv_len, Tensor kv_start, Tensor? out_slots, int n_kv_heads, Tensor(a!) plan_ws) -> ()",
+    "paged_decode": "(Tensor q, Tensor k_cache, Tensor v_cache, Tensor kv_indices, Tensor plan_ws, Tensor(a!) partial_ws, "
+                    "int n_q_heads, int n_kv_heads, float sm_scale) -> Tensor",
+    "paged_decode_qkv": "(Tensor qkv, Tensor positions, Tensor cos_sin, Tensor q_weight, Tensor k_weight, float eps, "
+                        "Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor kv_indices, Tensor plan_ws, Tensor(c!) partial_ws, "
+                        "int n_q_heads, int n_kv_heads, float sm_scale) -> Tensor",
+    "paged_decode_noalloc": "(Tensor q, Tensor k_cache, Tensor v_cache, Tensor kv_indices, Tensor kv_len, Tensor kv_start, "
+                            "int n_q_heads, int n_kv_heads, float sm_scale) -> Tensor",
+    # paged attention, prefill
+    "prefill_plan": "(Tensor qo_indptr, Tensor(a!) plan_ws) -> ()",
+    "paged_prefill": "(Tensor q, Tensor k_cache, Tensor v_cache, Tensor qo_indptr, Tensor kv_indptr, Tensor kv_indices, "
+                     "Tensor plan_ws, int n_q_heads, int n_kv_heads, float sm_scale) -> Tensor",
+    # projections of a decode step and the norm that sums their K-split partials
+    "linear_decode": "(Tensor x, Tensor w, int mode, int k_splits) -> Tensor",
+    "rmsnorm_splitk": "(Tensor partials, Tensor weight, float eps) -> Tensor",
+    "rmsnorm_splitk_residual": "(Tensor partials, Tensor residual, Tensor weight, float eps) -> (Tensor, Tensor)",
+    # device-resident block table
+    "block_table_write_rows": "(Tensor kv_indices, Tensor kv_indptr, Tensor rows, Tensor(a!) table) -> ()",
+    "decode_step_setup": "(Tensor step, int stride, int padded_batch, Tensor(a!) table, int pad_start, Tensor(b!) kv_start, "
+                         "Tensor(c!) kv_len, Tensor(d!) out_slots, Tensor(e!) positions, Tensor(f!) input_ids, Tensor? prev_ids) -> ()",
+}
+for _name, _sig in _DEFS.items():
+    _LIB.define(_name + _sig)
+
+
+def _ws(plan_ws, partial_ws, n_q_heads, n_kv_heads):
+    return ops.DecodeWorkspace.from_tensors(plan_ws, partial_ws, n_q_heads, n_kv_heads)
 
 
 def _store_kvcache(k, v, k_cache, v_cache, kv_indices):
@@ -44,6 +79,61 @@ def _sample(logits, temperatures, top_ks, top_ps, min_ps, seed, offset):
     return ops.sample(logits, temperatures, top_ks, top_ps, min_ps, seed, offset)
 
 
-for _name, _fn in (("store_kvcache", _store_kvcache), ("rmsnorm", _rmsnorm), ("rmsnorm_residual", _rmsnorm_residual),
-                   ("rope", _rope), ("silu_mul", _silu_mul), ("sample", _sample)):
-    _LIB.impl(_name, _fn, "CUDA")   # PyTorch-ROCm's device key is spelled CUDA
+def _sampler_probs(logits, temperatures, top_ks, top_ps, min_ps):
+    return ops.sampler_probs(logits, temperatures, top_ks, top_ps, min_ps)
+
+
+def _qknorm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, slots, k_cache, v_cache, n_q_heads, n_kv_heads):
+    return ops.qknorm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, slots, k_cache, v_cache, n_q_heads, n_kv_heads)
+
+
+def _decode_plan(kv_len, kv_start, out_slots: Optional[torch.Tensor], n_kv_heads, plan_ws):
+    ops.decode_plan(kv_len, kv_start, ops.DecodeWorkspace.from_tensors(plan_ws, None, 0, n_kv_heads), out_slots=out_slots)
+
+
+def _paged_decode(q, k_cache, v_cache, kv_indices, plan_ws, partial_ws, n_q_heads, n_kv_heads, sm_scale):
+    return ops.paged_decode(q, k_cache, v_cache, kv_indices, q.shape[0], _ws(plan_ws, partial_ws, n_q_heads, n_kv_heads), sm_scale)
+
+
+def _paged_decode_qkv(qkv, positions, cos_sin, q_weight, k_weight, eps, k_cache, v_cache, kv_indices, plan_ws, partial_ws,
+                      n_q_heads, n_kv_heads, sm_scale):
+    return ops.paged_decode_qkv(qkv, positions, cos_sin, q_weight, k_weight, eps, k_cache, v_cache, kv_indices, qkv.shape[0],
+                                _ws(plan_ws, partial_ws, n_q_heads, n_kv_heads), sm_scale)
+
+
+def _paged_decode_noalloc(q, k_cache, v_cache, kv_indices, kv_len, kv_start, n_q_heads, n_kv_heads, sm_scale):
+    return ops.paged_decode_noalloc(q, k_cache, v_cache, kv_indices, kv_len, kv_start, n_q_heads, n_kv_heads, sm_scale)
+
+
+def _prefill_plan(qo_indptr, plan_ws):
+    ops.prefill_plan(qo_indptr, plan_ws)
+
+
+def _paged_prefill(q, k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, plan_ws, n_q_heads, n_kv_heads, sm_scale):
+    return ops.paged_prefill(q, k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, plan_ws, n_q_heads, n_kv_heads, sm_scale)
+
+
+def _linear_decode(x, w, mode, k_splits):
+    return ops.linear_decode(x, w, mode=mode, k_splits=k_splits)
+
+
+def _rmsnorm_splitk(partials, weight, eps):
+    return ops.rmsnorm_splitk(partials, weight, eps)
+
+
+def _rmsnorm_splitk_residual(partials, residual, weight, eps):
+    return ops.rmsnorm_splitk(partials, weight, eps, residual=residual)
+
+
+def _block_table_write_rows(kv_indices, kv_indptr, rows, table):
+    ops.block_table_write_rows(kv_indices, kv_indptr, rows, table)
+
+
+def _decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids,
+                       prev_ids: Optional[torch.Tensor]):
+    ops.decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv_len, out_slots, positions, input_ids,
+                          prev_ids=prev_ids)
+
+
+for _name in _DEFS:
+    _LIB.impl(_name, globals()["_" + _name], "CUDA")   # PyTorch-ROCm's device key is spelled CUDA

@@ -91,3 +91,23 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
         assert "ABI version" in str(e)
     else:
         raise AssertionError("a version mismatch must raise")
+
+
+def test_every_kernel_entry_point_has_a_custom_op():
+    """`torch.ops.nvx.<name>` exists for every launching entry point of the C ABI (size queries and diagnostics
+    aside): the operator surface the Python host calls the kernels through."""
+    import torch
+
+    import nano_vllm_x_amd.torch_ops  # noqa: F401
+
+    op_of = {"nvx_store_kv": "store_kvcache", "nvx_rmsnorm": "rmsnorm", "nvx_rope": "rope", "nvx_silu_mul": "silu_mul",
+             "nvx_qknorm_rope_store": "qknorm_rope_store", "nvx_linear_decode": "linear_decode", "nvx_rmsnorm_splitk": "rmsnorm_splitk",
+             "nvx_decode_plan": "decode_plan", "nvx_paged_decode": "paged_decode", "nvx_paged_decode_qkv": "paged_decode_qkv",
+             "nvx_paged_decode_noalloc": "paged_decode_noalloc", "nvx_prefill_plan": "prefill_plan", "nvx_paged_prefill": "paged_prefill",
+             "nvx_sample": "sample", "nvx_sampler_probs": "sampler_probs", "nvx_block_table_write_rows": "block_table_write_rows",
+             "nvx_decode_step_setup": "decode_step_setup"}
+    helpers = {"nvx_abi_version", "nvx_last_error", "nvx_linear_decode_splits", "nvx_decode_plan_ws_ints", "nvx_decode_partial_ws_floats",
+               "nvx_prefill_plan_ws_ints", "nvx_sample_ws_bytes", "nvx_paged_decode_noalloc_max_batch"}
+    assert set(declared_symbols()) == set(op_of) | helpers, set(declared_symbols()) ^ (set(op_of) | helpers)
+    for sym, op in op_of.items():
+        assert hasattr(torch.ops.nvx, op), f"{sym} has no torch.ops.nvx.{op}"

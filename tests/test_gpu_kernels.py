@@ -791,3 +791,51 @@ def test_sampler_temperature_zero_is_greedy(ops):
         assert float(probs[r, am[r]]) == 1.0 and float(probs[r].sum()) == 1.0
     f32 = ops.sample(logits.float(), t, k, p, mp, seed=1, offset=1)
     assert torch.equal(f32[[0, 1, 2, 3, 5]], ids[[0, 1, 2, 3, 5]])
+
+
+def test_attention_path_custom_ops_match_the_direct_calls(ops):
+    """torch.ops.nvx.{decode_plan, paged_decode, paged_decode_noalloc, prefill_plan, paged_prefill, linear_decode,
+    rmsnorm_splitk}: operator objects over the same C-ABI launches (workspaces passed as tensors)."""
+    import nano_vllm_x_amd.torch_ops  # noqa: F401
+
+    gen = torch.Generator().manual_seed(31)
+    hq, hkv, slots = 16, 8, 4096
+    lens = np.asarray([700, 33, 1, 1500, 64], dtype=np.int32)
+    b = len(lens)
+    idx = torch.randperm(slots, generator=gen)[:int(lens.sum())].to(torch.int32).to(DEV)
+    kv_len = torch.from_numpy(lens).to(DEV)
+    kv_start = torch.from_numpy(np.concatenate(([0], np.cumsum(lens[:-1]))).astype(np.int64)).to(DEV)
+    kc = torch.randn(slots, hkv, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(slots, hkv, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    q = torch.randn(b, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    ws = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    ops.decode_plan(kv_len, kv_start, ws)
+    want = ops.paged_decode(q, kc, vc, idx, b, ws, 128 ** -0.5)
+    ws2 = ops.DecodeWorkspace(b, hq, hkv, DEV)
+    torch.ops.nvx.decode_plan(kv_len, kv_start, None, hkv, ws2.plan)
+    got = torch.ops.nvx.paged_decode(q, kc, vc, idx, ws2.plan, ws2.partial, hq, hkv, 128 ** -0.5)
+    assert torch.equal(got, want)
+    assert torch.equal(torch.ops.nvx.paged_decode_noalloc(q, kc, vc, idx, kv_len, kv_start, hq, hkv, 128 ** -0.5), want)
+    assert ops.DecodeWorkspace.from_tensors(ws2.plan, ws2.partial, hq, hkv).max_batch == b
+    # prefill
+    q_lens = [40, 130, 7]
+    t = sum(q_lens)
+    qo = torch.tensor(np.concatenate(([0], np.cumsum(q_lens))), dtype=torch.int32, device=DEV)
+    pidx = torch.randperm(slots, generator=gen)[:t].to(torch.int32).to(DEV)
+    qp = torch.randn(t, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    plan = ops.prefill_plan_ws(len(q_lens), DEV)
+    ops.prefill_plan(qo, plan)
+    want_p = ops.paged_prefill(qp, kc, vc, qo, qo, pidx, plan, hq, hkv, 128 ** -0.5)
+    plan2 = torch.zeros_like(plan)
+    torch.ops.nvx.prefill_plan(qo, plan2)
+    assert torch.equal(torch.ops.nvx.paged_prefill(qp, kc, vc, qo, qo, pidx, plan2, hq, hkv, 128 ** -0.5), want_p)
+    # a K-split projection and the norm that sums it
+    x = torch.randn(9, 2048, generator=gen).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(1024, 2048, generator=gen) * 0.02).to(torch.bfloat16).to(DEV)
+    g = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
+    s = ops.linear_decode_splits(1024, 2048)
+    parts = torch.ops.nvx.linear_decode(x, w, 2, s)
+    assert torch.equal(parts, ops.linear_decode(x, w, mode=2, k_splits=s))
+    y0, r0 = ops.rmsnorm_splitk(parts, g, 1e-6, residual=x[:, :1024].contiguous())
+    y1, r1 = torch.ops.nvx.rmsnorm_splitk_residual(parts, x[:, :1024].contiguous(), g, 1e-6)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
