@@ -11,6 +11,7 @@ are reported (`value` = nominal, `generated_tokens_per_s` = real).
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, TP = N)
 
 Also in the JSON line:
+  roofline_prefill -- nvx_paged_prefill on the workload's prefill step, against the dense bf16 MFMA peak
   roofline      -- the dominant hand-written kernel (paged decode attention, the variant the engine's
                    captured steps launch), replayed on the decode batches of this workload with HIP
                    events on the launch stream; algorithmic bytes = kv_rows * 2 (K,V) * kv_heads * 128 *
@@ -40,6 +41,7 @@ import torch
 METRIC = "output tokens/s (whole node), bench.py 256-req synthetic, Qwen3-0.6B @1/2/4/8 GPU"
 A100_PUBLISHED = 9032.37   # tok/s, 1x A100 40GB, reference README.md:100 (other hardware)
 HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, no sparsity
 
 
 def workload(num_seqs: int, max_in: int = 1024, max_out: int = 1024, seed: int = 0):
@@ -162,15 +164,80 @@ def decode_attention_roofline(runner, batches, reps: int = 14):
             "avg_algorithmic_bytes": int(total_bytes / max(1, launches))}
 
 
+def prefill_attention_roofline(runner, prompts, reps: int = 8):
+    """Time nvx_paged_prefill on the workload's prefill step (every prompt in one batch, nothing cached:
+    the step the timed passes run first), with HIP events around a hipGraph replay of `reps` launches over
+    consecutive layers of the real KV pool.  Flops: 2 MFMA products (scores, values) of 2 * 128 flops per
+    visible (query, key) pair and query head; the causal triangle only -- masked pairs are not counted."""
+    from nano_vllm_x_amd import ops
+
+    dev = runner.device
+    hq, hkv, layers = runner.num_heads, runner.num_kv_heads, runner.num_layers
+    kc, vc = runner.kv_cache.k_cache, runner.kv_cache.v_cache
+    lens = [len(p) for p in prompts]
+    total = sum(lens)
+    if total > kc.shape[1]:
+        return None
+    q = torch.randn(total, hq * 128, device=dev, dtype=torch.bfloat16)
+    out = torch.empty_like(q)
+    indptr = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).to(dev)
+    idx = torch.arange(total, dtype=torch.int32, device=dev)
+    plan = ops.prefill_plan_ws(len(lens), dev)
+    ops.prefill_plan(indptr, plan)
+    layer = 0
+
+    def launch_all():
+        nonlocal layer
+        for _ in range(reps):
+            ops.paged_prefill(q, kc[layer], vc[layer], indptr, indptr, idx, plan, hq, hkv, 128 ** -0.5, out=out)
+            layer = (layer + 1) % layers
+
+    launch_all()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            launch_all()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flop = 4 * hq * 128 * sum(l * (l + 1) // 2 for l in lens)
+    return {"bound": "mfma", "achieved": round(flop / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "paged_prefill_kernel<2,4> (nvx_paged_prefill)", "launches": reps,
+            "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops": flop,
+            "batch": f"{len(lens)} prompts, {total} tokens, causal, nothing cached"}
+
+
 def _pmc_traffic(kernel: str):
-    """HBM bytes per launch from rocprofv3 PMC passes, if a summary has been committed."""
+    """HBM bytes per launch from rocprofv3 PMC passes, if a summary has been committed AND was taken from the
+    kernel source this run uses (the summary records the source file's SHA-256); a summary of another revision
+    is reported as None rather than passed off as this kernel's traffic."""
+    import hashlib
+
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            d = json.load(f)
-        if kernel in d:   # the main kernel and the merge kernel that completes it
-            return int(d[kernel]) + int(d.get("decode_merge_kernel", 0))
-    return None
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    stamp = d.get("kernel_source")
+    if not stamp or kernel not in d:
+        return None
+    try:
+        with open(os.path.join(ROOT, stamp["file"]), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest() != stamp["sha256"]:
+                return None
+    except OSError:
+        return None
+    return int(d[kernel]) + int(d.get("decode_merge_kernel", 0))   # the main kernel and the merge kernel that completes it
 
 
 def config1_workload():
@@ -340,6 +407,8 @@ def main():
             result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
         result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x14 graph-replayed launches over rotating layers"
         result["decode_kv_rows_per_step"] = kv_rows
+        with torch.inference_mode():
+            result["roofline_prefill"] = prefill_attention_roofline(eng.model_runner, prompts)
     gpu_c1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         gpu_c1 = config1_on_gpu(llm)

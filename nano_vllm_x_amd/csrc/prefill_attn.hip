@@ -17,6 +17,8 @@
 //            so the online-softmax rescale is a per-lane scalar multiply.
 #include "nvx_dev.h"
 
+#include <type_traits>
+
 #define PF_KVBLK 64
 #define PF_LOG2E 1.4426950408889634f
 
@@ -261,18 +263,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         }
 
         const int key_base = tile * PF_KVBLK;
-        if (key_base <= wave_last_key) {   // wave-uniform: otherwise nothing in this tile is visible to this wave
+        // One tile for this wave: NKB = 2 when both 32-key blocks hold keys some query of the wave sees, 1 when the
+        // second block lies wholly beyond the causal diagonal for all of them (half the waves of a workgroup on
+        // its last tile): its score and value MFMAs, exponentials and LDS reads are then not issued at all.
+        auto tile_body = [&](auto nkb_tag) __attribute__((always_inline)) {
+        constexpr int NKB = decltype(nkb_tag)::value;
 
         // ---- S^T = K . Q^T ----
-        // all sixteen K fragments are requested before the first MFMA, and the two 32-key blocks
-        // alternate so that no MFMA waits for the one before it
-        nvx_f32x16 st[2];
-        nvx_u32x4 kf[2][8];
+        // all K fragments are requested before the first MFMA, and the 32-key blocks alternate so that no MFMA
+        // waits for the one before it
+        nvx_f32x16 st[NKB];
+        nvx_u32x4 kf[NKB][8];
         // fragment ks of key row l32 (+32 for the second block) sits at piece (2 ks + half) ^ (key & 15): one
         // per-tile base, the k-step applied as an XOR on the address bits, the block as an immediate offset
         const unsigned kfrag0 = k_lds + k_lane_off;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
                 kf[kb][ks] = pf_lds_read16((kfrag0 ^ (ks << 5)) + kb * 32 * 256);
@@ -282,19 +288,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, kf[kb][ks]), qf[ks], st[kb], 0, 0, 0);
-        // scheduling order for this region: the sixteen LDS reads, then the sixteen MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        // ---- mask, online softmax (this lane: one query, 32 of the tile's 64 keys) ----
+        // scheduling order for this region: the LDS reads, then the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8 * NKB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NKB, 0);
+        // ---- mask, online softmax (this lane: one query, 16 of each 32-key block) ----
         // Scores stay unscaled; the scale rides on the fused multiply-add inside the exponent.  Only
         // tiles that cross the causal diagonal (or the end of the sequence) pay for the mask.
         const int vis = q_ok ? qi + offset : -1;   // last visible key index of this lane's query
-        if (key_base + PF_KVBLK - 1 > wave_first_vis) {   // wave-uniform
+        if (key_base + 32 * NKB - 1 > wave_first_vis) {   // wave-uniform
             asm volatile("" : : : "memory");   // keeps the branch: as selects on every tile the mask costs 96 VALU ops
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -328,8 +334,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         // first two (kb, s2) groups are requested before the exponentials and land under them; each group
         // of four MFMAs is followed by the reads of the group two ahead.
         typedef __attribute__((ext_vector_type(8))) short s16x8;
+        constexpr int NGRP = 2 * NKB;   // groups of 16 keys
         const unsigned vfrag0 = v_lds + v_lane_off;
-        s16x8 vf[4][4];
+        s16x8 vf[NGRP][4];
         auto read_group = [&](int grp_i) {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         read_group(0);
         read_group(1);
         __builtin_amdgcn_sched_barrier(0);
-        nvx_bf16x8 pf[4];
+        nvx_bf16x8 pf[NGRP];
         auto probabilities = [&](int gi) {   // P^T of 16 keys: 8 exponentials per lane
             const int kb = gi >> 1, s2 = gi & 1;
             uint32_t w[4];
@@ -360,13 +367,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         // the four MFMAs of a group run on the matrix pipe while the vector ALU makes the next group's
         // probabilities: one MFMA, then a share of the exponentials, four times over
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
+        for (int gi = 0; gi < NGRP; ++gi) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
                 o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, vf[gi][d]), pf[gi], o_acc[d], 0, 0, 0);
-            if (gi + 1 < 4) probabilities(gi + 1);
-            if (gi + 2 < 4) read_group(gi + 2);
-            if (gi + 1 < 4) {
+            if (gi + 1 < NGRP) probabilities(gi + 1);
+            if (gi + 2 < NGRP) read_group(gi + 2);
+            if (gi + 1 < NGRP) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -375,7 +382,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        }
+        };
+        if (key_base + 32 <= wave_last_key) tile_body(std::integral_constant<int, 2>{});        // wave-uniform
+        else if (key_base <= wave_last_key) tile_body(std::integral_constant<int, 1>{});        // else: nothing visible
         pf_wait_copies();
         __syncthreads();   // tile + 1 and the ids of tile + 2 visible; this tile's buffer free
         { const unsigned t0 = ring0; ring0 = ring1; ring1 = t0; }
