@@ -137,6 +137,18 @@ __device__ __forceinline__ void pf_gather(unsigned ids, int krow0, unsigned n_sl
     for (int p = 0; p < PASSES; ++p) pf_gather_one(id[p], n_slots, kbase, vbase, row_bytes, k_dst + p * STEP, v_dst + p * STEP);
 }
 
+#ifdef PF_STAMPS
+// Build-time instrumentation (tools/build_variant.sh ... "-DPF_STAMPS"): shader-clock stamps of waves 0 and 3 of the
+// workgroups of query blocks 120 and 121 (kv head 0) at eight points of tiles 16..47, read back with nvx_debug_pf_stamps.
+// Never in the shipped library.
+__device__ unsigned long long pf_stamps[2 * 2 * 32 * 8];
+extern "C" int nvx_debug_pf_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pf_stamps), sizeof(pf_stamps)); }
+#define PF_STAMP(k) do { if (stamp_on && tile >= 16 && tile < 48 && lane == 0) \
+    pf_stamps[(((gblk - 120) * 2 + (wave ? 1 : 0)) * 32 + (tile - 16)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PF_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 template <int G, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
@@ -253,7 +265,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     __syncthreads();
     { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
     // at the top of tile t: ids0 holds the ids of tile t + 1, ids1 is free (its ids were used a tile ago)
+#ifdef PF_STAMPS
+    const bool stamp_on = (gblk == 120 || gblk == 121) && head == 0 && (wave == 0 || wave == 3);
+#endif
     for (int tile = 0; tile < n_tiles; ++tile) {
+        PF_STAMP(0);
         const unsigned k_lds = ring0;   // LDS byte addresses
         const unsigned v_lds = k_lds + PF_KVBLK * 256;
         if (tile + 1 < n_tiles) {   // the other buffer held tile t - 1: every wave left it before the last barrier
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
             if (tile + 2 < n_tiles && wave == 0) pf_fetch_slot_ids(seq_slots, tile + 2, lkv, lane, ids1);
         }
 
+        PF_STAMP(1);
         const int key_base = tile * PF_KVBLK;
         // One tile for this wave: NKB = 2 when both 32-key blocks hold keys some query of the wave sees, 1 when the
         // second block lies wholly beyond the causal diagonal for all of them (half the waves of a workgroup on
@@ -293,6 +310,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         // scheduling order for this region: the LDS reads, then the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 8 * NKB, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8 * NKB, 0);
+        PF_STAMP(2);
         // ---- mask, online softmax (this lane: one query, 16 of each 32-key block) ----
         // Scores stay unscaled; the scale rides on the fused multiply-add inside the exponent.  Only
         // tiles that cross the causal diagonal (or the end of the sequence) pay for the mask.
@@ -324,6 +342,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
         }
+        PF_STAMP(3);
         // ---- P^T, then O^T += V^T . P^T ----
         // V^T fragment element j of lane half h is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the 32-key block; the
         // transpose read hands lane i of a 16-lane group column i of a 4-key x 16-dim block.  The lane
@@ -364,6 +383,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         };
         probabilities(0);
         __builtin_amdgcn_sched_barrier(0);
+        PF_STAMP(4);
         // the four MFMAs of a group run on the matrix pipe while the vector ALU makes the next group's
         // probabilities: one MFMA, then a share of the exponentials, four times over
 #pragma unroll
@@ -382,11 +402,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        PF_STAMP(5);
         };
         if (key_base + 32 <= wave_last_key) tile_body(std::integral_constant<int, 2>{});        // wave-uniform
         else if (key_base <= wave_last_key) tile_body(std::integral_constant<int, 1>{});        // else: nothing visible
         pf_wait_copies();
+        PF_STAMP(6);
         __syncthreads();   // tile + 1 and the ids of tile + 2 visible; this tile's buffer free
+        PF_STAMP(7);
         { const unsigned t0 = ring0; ring0 = ring1; ring1 = t0; }
         { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
     }
