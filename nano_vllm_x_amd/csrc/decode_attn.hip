@@ -20,6 +20,7 @@
 #include "rope_dev.h"
 
 #include <mutex>
+#include <stdlib.h>
 
 #define DEC_TARGET_UNITS 2048   // work units (chunk x kv head) the plan aims for
 #define DEC_MIN_CHUNK 128       // tokens
@@ -114,8 +115,10 @@ extern "C" int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, c
     NVX_REQUIRE(plan_ws_ints >= nvx_decode_plan_ws_ints(batch, n_kv_heads), NVX_ENOSPACE,
                 "nvx_decode_plan: plan workspace too small (%lld < %lld ints)", (long long)plan_ws_ints,
                 (long long)nvx_decode_plan_ws_ints(batch, n_kv_heads));
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("NVX_DEC_TARGET"); target = e ? atoi(e) : DEC_TARGET_UNITS; if (target < 64 || target > 2048) target = DEC_TARGET_UNITS; }
     hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_len, kv_start, out_slots, (int)batch,
-                       n_kv_heads, plan_ws, (int)dec_max_items(batch, n_kv_heads), DEC_TARGET_UNITS);
+                       n_kv_heads, plan_ws, (int)dec_max_items(batch, n_kv_heads), target);
     return nvx_check_launch("nvx_decode_plan");
 }
 
@@ -420,6 +423,331 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Helpers of the LDS-ring variant below.
+typedef __attribute__((address_space(3))) const nvx_u32x4 dec_lds_u4;
+__device__ __forceinline__ nvx_u32x4 dec_lds_read16(unsigned addr) { return *reinterpret_cast<dec_lds_u4*>((uintptr_t)addr); }
+__device__ __forceinline__ unsigned dec_lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+// 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS starting at a wave-uniform address, as a streaming
+// (non-temporal) read.  Issued from inline assembly: the compiler's own LDS-DMA builtin makes every later LDS read wait
+// for the copy.  m0 has no other user in this kernel.
+__device__ __forceinline__ void dec_dma16(const char* g, unsigned lds_addr) {
+    const unsigned uni = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(uni) : "memory");
+}
+// at most `n` of this wave's vector-memory operations still in flight (operations complete in order)
+template <int N>
+__device__ __forceinline__ void dec_wait_copies() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+// ---------------------------------------------------------------------------------------------
+// Variant for wide query groups (G >= 8): rows in flight held by LDS, products on the matrix cores.
+//
+// In the kernel above a wave's rows in flight are registers and every (token, query head) pair costs about 24 vector
+// instructions on a quarter-wave, so both the bytes a CU keeps in flight and the vector ALU time scale against it as G
+// grows: at 8 query heads per kv head it needs 232 VGPRs (two waves per SIMD, 32 KB in flight per CU where the HBM
+// latency wants about 50) and four times the arithmetic of G = 2.  Here each wave owns a ring of NS stages of 16 tokens
+// (K rows, then V rows: 8 KB) in LDS and fills it with LDS-DMA copies (pool -> LDS, no registers), NS - 1 stages
+// ahead of the one it is reducing; the copies are counted (s_waitcnt vmcnt(8 x stages still wanted in flight)),
+// never drained.  Slot ids are wave-uniform scalar loads issued one iteration ahead (their own counter: no wait on
+// them touches the copies).  With the rows in LDS they can be read in MFMA operand order, and the G query heads
+// become the N side of small matrix products: per stage and wave, S^T[16 tokens x 16 head slots] = K . Q^T is four
+// v_mfma_f32_16x16x32_bf16 (K rows read from LDS as the A operand, Q in registers as B, head slots >= G zero); the
+// accumulator layout of S IS the B operand layout of v_mfma_f32_16x16x16_bf16 (lane: head l16, tokens 4q..4q+3), so P
+// (rounded to bf16, as in the prefill kernel) goes back in without leaving the lane, and O^T[128 dims x 16 head slots]
+// += V^T . P is eight of those with V^T read by ds_read_b64_tr_b16.  Vector work per stage is the softmax of four
+// scores per lane, whatever G is.
+// LDS rows are XOR-swizzled so that the operand reads are conflict free: position p of K row r holds piece
+// p ^ (r & 15), of V row r piece p ^ ((r & 7) << 1); the copy writes consecutive positions, so the swizzle is applied
+// to the global address a lane fetches from.
+// Measured on the bench's decode batches (pair with the merge launch, us, this kernel vs the one above): 64 q / 8 kv
+// heads 69.5 vs 115.5 at 123 sequences, 38.7 vs 53.3 at 31, 12.1 vs 16.8 at 2; 16 / 2 heads 28.8 vs 41.0, 16.2 vs 22.5,
+// 11.8 vs 16.3.  At G = 4 the two are level (32 / 8 heads: 64.5 vs 69.6, 32.7 vs 30.7, 11.0 vs 12.4) and at G = 2 the
+// register kernel is faster (its four workgroups per CU hide the per-unit start-up better than the two that 64 KB of
+// rings allow): G <= 4 stays there, except G = 4 with one or two kv heads (4 / 1 heads: 12.2 vs 13.7 us on average).
+#define DEC_M_TOKENS 16
+#define DEC_M_STAGE_BYTES (DEC_M_TOKENS * 512)
+#ifndef DEC_M_NS
+#define DEC_M_NS 2
+#endif
+#ifndef DEC_M_WPS
+#define DEC_M_WPS 2
+#endif
+typedef __attribute__((ext_vector_type(4))) short dec_s16x4;
+typedef __attribute__((address_space(3))) dec_s16x4 dec_lds_s16x4;
+__device__ __forceinline__ dec_s16x4 dec_lds_read_tr(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<dec_lds_s16x4*>((uintptr_t)addr));
+}
+typedef __attribute__((address_space(3))) nvx_u32x4 dec_lds_w4;
+__device__ __forceinline__ void dec_lds_write16(unsigned addr, nvx_u32x4 v) { *reinterpret_cast<dec_lds_w4*>((uintptr_t)addr) = v; }
+
+#ifdef DEC_STAMPS
+// Build-time instrumentation (tools/build_variant.sh ... "-DDEC_STAMPS"): shader-clock stamps of the four waves of
+// workgroups 0..15 at four points of their first 16 stages, read back with nvx_debug_dec_stamps.  Never in the shipped library.
+__device__ unsigned long long dec_stamps[16 * 4 * 16 * 4];
+extern "C" int nvx_debug_dec_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dec_stamps), sizeof(dec_stamps)); }
+#define DEC_STAMP(k) do { if (blockIdx.x < 16 && j < 16 && lane == 0) \
+    dec_stamps[((blockIdx.x * 4 + wave) * 16 + j) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
+
+template <int G, bool QKV, int NS>
+__global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
+    const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ kv_indices,
+    const int32_t* __restrict__ plan, float* __restrict__ partial, uint16_t* __restrict__ out, int hkv,
+    float scale_log2, DecQkv fx) {
+    static_assert(G >= 1 && G <= 16, "query heads per kv head fill the 16 columns of the products");
+    static_assert(NS >= 2 && NS <= 3, "ring depth");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dec_smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int quarter = lane >> 4, l16 = lane & 15;
+    const int hq_total = hkv * G;
+    const unsigned row_bytes = (unsigned)hkv * 256u;
+    const unsigned n_slots_u = n_slots > 0xffffffffll ? 0xffffffffu : (unsigned)n_slots;
+    const int32_t* recs = plan + 8;
+    const unsigned ring = dec_lds_addr(dec_smem) + (unsigned)wave * (NS * DEC_M_STAGE_BYTES);
+    float (*mine_out)[16][10] = reinterpret_cast<float (*)[16][10]>(dec_smem + (size_t)wave * (NS * DEC_M_STAGE_BYTES));
+    static_assert(G * 16 * 10 * 4 <= NS * DEC_M_STAGE_BYTES, "merge rows fit the wave's ring");
+    // per-lane parts of the operand addresses inside a stage
+    const unsigned k_lane = (unsigned)l16 * 256u;                                   // K row l16; piece XOR applied per k-step
+    const int v_row = 4 * quarter + (l16 >> 2);                                     // V^T block: this lane addresses token 4q + (i >> 2)
+    const unsigned v_lane = 2048u * 2u + (unsigned)v_row * 256u + 8u * (l16 & 1);   // V rows start 4 KB into the stage
+    const int v_pc = (l16 & 3) >> 1, v_sw = (v_row & 7) << 1;
+
+    int unit = blockIdx.x;
+    const int n_units = plan[0] * hkv;
+    while (unit < n_units) {
+        const int item = unit / hkv, head = unit % hkv;
+        const int32_t* rec = recs + (int64_t)DEC_REC_INTS * item;
+        const int b = __builtin_amdgcn_readfirstlane(rec[0]), n = __builtin_amdgcn_readfirstlane(rec[1]);
+        const int nch = __builtin_amdgcn_readfirstlane(rec[2]);
+        const int64_t abs = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rec[5]) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rec[4]));
+        const int32_t* idx_base = kv_indices + abs;
+        const char* kb = reinterpret_cast<const char*>(k_cache) + head * 256;
+        const char* vb = reinterpret_cast<const char*>(v_cache) + head * 256;
+        const int slot_new = QKV ? __builtin_amdgcn_readfirstlane(rec[7]) : -1;
+        const bool own_new = QKV && slot_new >= 0 && (long long)slot_new < (long long)n_slots && n > 0;
+        const int n_pool = own_new ? n - 1 : n;
+        const int n_stages = (n_pool + DEC_M_TOKENS - 1) / DEC_M_TOKENS;
+        const int my_stages = n_stages > wave ? (n_stages - wave + 3) >> 2 : 0;   // stages wave, wave + 4, ...
+
+        // One stage: the ids of its 16 tokens travel first (scalar loads, one iteration before the rows they name, so
+        // that their round trip is not in front of the copies), then eight copies of 1 KB (K tokens 0-3, V 0-3, K 4-7,
+        // ...: quarter-wave q moves the row of token 4a + q, lane p of it the piece that belongs at position p).
+        struct StageIds { unsigned id[DEC_M_TOKENS]; unsigned ok; };
+        auto load_ids = [&](int stage) -> StageIds {
+            StageIds r;
+            r.ok = 0;
+#pragma unroll
+            for (int t = 0; t < DEC_M_TOKENS; ++t) {
+                const int at = stage * DEC_M_TOKENS + t;
+                const unsigned v = (unsigned)idx_base[at < n_pool ? at : n_pool - 1];
+                const bool good = at < n_pool && v < n_slots_u;
+                r.ok |= good ? (1u << t) : 0u;
+                r.id[t] = good ? v : 0u;
+            }
+            return r;
+        };
+        auto issue = [&](const StageIds& ids, unsigned dst) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned slot = quarter == 0 ? ids.id[4 * a] : quarter == 1 ? ids.id[4 * a + 1] : quarter == 2 ? ids.id[4 * a + 2] : ids.id[4 * a + 3];
+                const unsigned long long off = (unsigned long long)slot * row_bytes;
+                const int t = 4 * a + quarter;
+                dec_dma16(kb + off + ((l16 ^ (t & 15)) << 4), dst + a * 1024);
+                dec_dma16(vb + off + ((l16 ^ ((t & 7) << 1)) << 4), dst + 4096 + a * 1024);
+            }
+        };
+
+        unsigned okq[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) okq[k] = 0;
+#pragma unroll
+        for (int k = 0; k < NS - 1; ++k)
+            if (k < my_stages) { const StageIds ids = load_ids(wave + 4 * k); okq[k] = ids.ok; issue(ids, ring + k * DEC_M_STAGE_BYTES); }
+        StageIds ahead_ids;
+        ahead_ids.ok = 0;
+#pragma unroll
+        for (int t = 0; t < DEC_M_TOKENS; ++t) ahead_ids.id[t] = 0;
+        if (NS - 1 < my_stages) ahead_ids = load_ids(wave + 4 * (NS - 1));
+
+        // Q^T as the B operand of the score products: lane (q, l16) holds dims 32 ks + 8 q .. +7 of head l16 (zero
+        // for l16 >= G).  In the QKV variant the heads are normalised and rotated first, 16 lanes per head as the
+        // stand-alone kernel does it, and turned around through the one stage of the ring that is not in flight yet.
+        nvx_u32x4 qb[4];
+        const uint16_t* qrow = q + (int64_t)b * q_stride;
+        const float* cs = nullptr;
+        if (QKV) {
+            cs = fx.cos_sin + clamp_pos(fx.positions[b], fx.max_pos) * 128;
+            const unsigned qarea = ring + (NS - 1) * DEC_M_STAGE_BYTES;
+#pragma unroll
+            for (int g0 = 0; g0 < G; g0 += 4) {
+                const int g = g0 + quarter;
+                if (g < G) {
+                    const HalfQuad qraw = load_half_quads(qrow + (head * G + g) * 128, l16);
+                    const uint4 o = norm_rotate_interleave(qraw, half_quad_sumsq(qraw), fx.q_weight, fx.eps, cs, l16);
+                    dec_lds_write16(qarea + g * 256 + l16 * 16, nvx_u32x4{o.x, o.y, o.z, o.w});
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qb[ks] = dec_lds_read16(qarea + (l16 < G ? l16 : 0) * 256 + (4 * ks + quarter) * 16);
+                if (l16 >= G) qb[ks] = nvx_u32x4{0u, 0u, 0u, 0u};
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qb[ks] = *reinterpret_cast<const nvx_u32x4*>(qrow + (head * G + (l16 < G ? l16 : 0)) * 128 + 32 * ks + 8 * quarter);
+                if (l16 >= G) qb[ks] = nvx_u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        // Q is complete (and its turn through the ring over) before the loop starts counting copies: a wait the
+        // compiler places at the first use inside the loop would drain the ring on every iteration.
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qb[ks]));
+
+        nvx_f32x4 o_acc[8];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) o_acc[blk] = nvx_f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;   // of head l16; m_run is the same in the four quarter-waves
+
+        // one stage of 16 tokens at LDS address `base` (K rows, then V rows), `okm`: which tokens are real keys
+        auto reduce_stage = [&](unsigned base, unsigned okm) {
+            nvx_f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const nvx_u32x4 a = dec_lds_read16(base + k_lane + (((4 * ks + quarter) ^ l16) << 4));
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nvx_bf16x8, a), __builtin_bit_cast(nvx_bf16x8, qb[ks]), sacc, 0, 0, 0);
+            }
+            const unsigned mine4 = (okm >> (4 * quarter)) & 15u;   // tokens 4q .. 4q+3
+            float sv[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sv[r] = (mine4 >> r) & 1u ? sacc[r] * scale_log2 : -INFINITY;
+                mx = fmaxf(mx, sv[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float mref = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) o_acc[blk] *= alpha;
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sv[r] - mref); l_run += p[r]; }
+            const uint32_t p01 = pack_bf16x2(p[0], p[1]), p23 = pack_bf16x2(p[2], p[3]);
+            const dec_s16x4 pb = __builtin_bit_cast(dec_s16x4, make_uint2(p01, p23));
+            // value rows of tokens that are not keys may hold anything (0 x NaN = NaN): cleared in the operand
+            const uint32_t vm01 = ((mine4 & 1u) ? 0xffffu : 0u) | ((mine4 & 2u) ? 0xffff0000u : 0u);
+            const uint32_t vm23 = ((mine4 & 4u) ? 0xffffu : 0u) | ((mine4 & 8u) ? 0xffff0000u : 0u);
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                const dec_s16x4 vt = dec_lds_read_tr(base + v_lane + (((2 * blk + v_pc) ^ v_sw) << 4));
+                uint2 vw = __builtin_bit_cast(uint2, vt);
+                vw.x &= vm01; vw.y &= vm23;
+                o_acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(dec_s16x4, vw), pb, o_acc[blk], 0, 0, 0);
+            }
+        };
+
+        int slot_cur = 0, slot_next = (NS - 1) % NS;
+        for (int j = 0; j < my_stages; ++j) {
+            DEC_STAMP(0);
+            const int ahead = j + NS - 1;
+            if (ahead < my_stages) { okq[NS - 1] = ahead_ids.ok; issue(ahead_ids, ring + slot_next * DEC_M_STAGE_BYTES); }
+            if (ahead + 1 < my_stages) ahead_ids = load_ids(wave + 4 * (ahead + 1));   // lands under the wait below
+            DEC_STAMP(1);
+            const int later = my_stages - 1 - j < NS - 1 ? my_stages - 1 - j : NS - 1;
+            if (later >= 2) dec_wait_copies<16>();
+            else if (later == 1) dec_wait_copies<8>();
+            else dec_wait_copies<0>();
+            DEC_STAMP(2);
+            reduce_stage(ring + slot_cur * DEC_M_STAGE_BYTES, okq[0]);
+            DEC_STAMP(3);
+#pragma unroll
+            for (int k = 0; k < NS - 1; ++k) okq[k] = okq[k + 1];
+            slot_cur = slot_cur + 1 == NS ? 0 : slot_cur + 1;
+            slot_next = slot_next + 1 == NS ? 0 : slot_next + 1;
+        }
+        dec_wait_copies<0>();
+
+        if (QKV && own_new) {   // the new token: made from the raw projection, stored in the pool, and reduced by wave 0
+                                // as a stage of its own with one real key (row 0 of the wave's first stage)
+            const nvx_u32x4 k_new = dec_new_key(qrow, hq_total, head, fx, cs, l16);
+            const nvx_u32x4 v_new = *reinterpret_cast<const nvx_u32x4*>(qrow + (hq_total + hkv + head) * 128 + l16 * 8);
+            if (tid < 16) {
+                const int64_t at = ((int64_t)slot_new * hkv + head) * 128 + l16 * 8;
+                *reinterpret_cast<nvx_u32x4*>(fx.k_cache_w + at) = k_new;
+                *reinterpret_cast<nvx_u32x4*>(fx.v_cache_w + at) = v_new;
+            }
+            if (wave == 0) {
+                if (quarter == 0) {   // row 0: no swizzle
+                    dec_lds_write16(ring + l16 * 16, k_new);
+                    dec_lds_write16(ring + 4096 + l16 * 16, v_new);
+                }
+                reduce_stage(ring, 1u);
+            }
+        }
+
+        // the four quarter-waves saw different tokens: their row sums add up (the maxima already agree)
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        // hand the wave's state to the workgroup through the (dead) ring: [head][16-byte piece] -> m, l, acc[8];
+        // this lane holds dims 16 blk + 4 q .. +3 of head l16: half of piece 2 blk + (q >> 1)
+        if (l16 < G) {
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                float* dst = mine_out[l16][2 * blk + (quarter >> 1)];
+                if ((quarter & 1) == 0) { dst[0] = m_run; dst[1] = l_run; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[2 + 4 * (quarter & 1) + r] = o_acc[blk][r];
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * G) {
+            const int g = tid >> 4, pc = tid & 15;
+            const float* src[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                src[w] = reinterpret_cast<const float*>(dec_smem + (size_t)w * (NS * DEC_M_STAGE_BYTES)) + (g * 16 + pc) * 10;
+            float mall = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) mall = fmaxf(mall, src[w][0]);
+            const float mr = mall == -INFINITY ? 0.f : mall;
+            float lsum = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float sc = __builtin_amdgcn_exp2f(src[w][0] - mr);
+                lsum += src[w][1] * sc;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += src[w][2 + j] * sc;
+            }
+            const int hq = head * G + g;
+            if (nch == 1) {
+                const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+                uint16_t* dst = out + ((int64_t)b * hq_total + hq) * 128 + pc * 8;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv),
+                                                            pack_bf16x2(o[4] * inv, o[5] * inv), pack_bf16x2(o[6] * inv, o[7] * inv));
+            } else {
+                float* dst = partial + ((int64_t)item * hq_total + hq) * DEC_PART_STRIDE;
+                *reinterpret_cast<float4*>(dst + pc * 8) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(dst + pc * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                if (pc == 0) { dst[128] = mall; dst[129] = lsum; }
+            }
+        }
+        __syncthreads();   // the rings are free again
+        unit += gridDim.x;
+    }
+}
+
 // Combine the partials of sequences that were split over several chunks: one 128-thread block per
 // (sequence, query head), thread d owns output element d.  Blocks of unsplit sequences exit at once.
 // The kernel is a chain of dependent loads and nothing else, so the chain is kept at two hops: the
@@ -491,6 +819,31 @@ static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, 
     } while (0)
     // tokens per quarter-wave per tile: plain variant / variant fed with the raw projection (which keeps
     // more values live across the loop, so it takes a smaller tile to stay within the same registers)
+    static int ring_mode = -1;   // NVX_DEC_RING: 0 = rows in registers for every G, 1 = LDS ring + MFMA for every G, unset = by G
+    if (ring_mode < 0) { const char* e = getenv("NVX_DEC_RING"); ring_mode = e ? (atoi(e) ? 1 : 0) : 2; }
+    // by G: wide groups, and G = 4 where a launch moves few bytes (one or two kv heads per rank: the kernel's shorter
+    // vector work per unit is what counts there; at 8 kv heads the two kernels are level)
+    if (ring_mode == 1 || (ring_mode == 2 && (g >= 8 || (g >= 4 && n_kv_heads <= 2)))) {
+        constexpr int NS = DEC_M_NS;
+        const size_t smem = (size_t)4 * NS * DEC_M_STAGE_BYTES;
+#define NVX_DEC_MFMA_K(GG)                                                                                                        \
+        do {                                                                                                                      \
+            if (fx) hipLaunchKernelGGL((paged_decode_mfma_kernel<GG, true, NS>), dim3(grid), dim3(256), smem, st, (const uint16_t*)q, \
+                                       q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, \
+                                       partial_ws, (uint16_t*)out, n_kv_heads, scale_log2, *fx);                                  \
+            else hipLaunchKernelGGL((paged_decode_mfma_kernel<GG, false, NS>), dim3(grid), dim3(256), smem, st, (const uint16_t*)q,   \
+                                    q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, \
+                                    partial_ws, (uint16_t*)out, n_kv_heads, scale_log2, none);                                    \
+        } while (0)
+        switch (g) {
+            case 1: NVX_DEC_MFMA_K(1); break;
+            case 2: NVX_DEC_MFMA_K(2); break;
+            case 4: NVX_DEC_MFMA_K(4); break;
+            case 8: NVX_DEC_MFMA_K(8); break;
+            default: return nvx_fail(NVX_EUNSUPPORTED, "%s: query/kv head ratio %d not in {1,2,4,8}", who, g);
+        }
+#undef NVX_DEC_MFMA_K
+    } else
     switch (g) {
         case 1: NVX_DEC(1, 4, 4); break;
         case 2: NVX_DEC(2, 4, 2); break;   // plain: 112 VGPRs, four workgroups per CU; measured best of TPQ 2/4/8/16

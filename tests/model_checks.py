@@ -21,23 +21,23 @@ FLOOR = 2.0 ** -8     # one bf16 ulp of the largest logit, at best: the bound wh
 
 # name -> observed max|diff| / max|want| on MI355X
 MEASURED: dict = {
-    "config1_cpu_fp32_engine_vs_hip_engine": 0.0177136,
+    "config1_cpu_fp32_engine_vs_hip_engine": 0.0188121,
     "config3_prefix_reuse_vs_recompute": 0,
     "config5_chunked_vs_one_step_prefill": 0,
-    "forced_collectives_vs_one_rank": 0.0042735,
+    "forced_collectives_vs_one_rank": 0.00877193,
     "fused_vs_library[0.6B/tp2]": 0.00506073,
     "fused_vs_library[0.6B/tp4]": 0.00408021,
     "fused_vs_library[0.6B/tp8]": 0,
     "fused_vs_library[config3_qwen3_8b_tp1]": 0.00865801,
     "fused_vs_library[config4_qwen3_8b_tp8]": 0.00775194,
-    "fused_vs_library[config5_qwen3_32b_tp4_stage]": 0,
+    "fused_vs_library[config5_qwen3_32b_tp4_stage]": 0.00843882,
     "fused_vs_library[hidden512]": 0.00441505,
     "g7_k_cache_vs_reference": 0.00680272,
     "g7_reference_vs_hip_eager": 0.00840336,
     "g7_reference_vs_hip_unfused": 0.00840336,
     "g7_unfused_vs_fused": 0,
     "pp2_vs_one_rank": 0,
-    "tp2_vs_one_rank": 0.00948661,
+    "tp2_vs_one_rank": 0.011239,
 }
 
 _OBSERVED: dict = {}

@@ -38,6 +38,18 @@ def attn_close(got: torch.Tensor, want_f32: torch.Tensor, p_bf16_vmax: float = 0
     assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outside tolerance; max err {(got - want).abs().max():.3e}"
 
 
+def decode_p_rounding(hq: int, hkv: int, vc: torch.Tensor) -> float:
+    """max|V| when the decode kernel for this head ratio rounds the probabilities to bf16 before the value product (the
+    matrix-core variant -- used from 8 query heads per kv head, and from 4 with one or two kv heads -- as the prefill
+    kernel and FlashInfer's tensor-core decode do); 0 for the variant that keeps them in fp32."""
+    g = hq // hkv
+    return float(vc.float().abs().max()) if g >= 8 or (g >= 4 and hkv <= 2) else 0.0
+
+
+# the two decode kernels: rows in registers + vector arithmetic (G <= 4), rows through LDS + MFMA (G >= 8)
+DECODE_KERNEL_SHAPES = [(16, 8), (16, 2)]
+
+
 # -----------------------------------------------------------------------------------------------
 def test_store_kv_golden(ops):
     g = golden_npz("g4_store_kv.npz")
@@ -195,7 +207,7 @@ def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
     ops.decode_plan(kv_len, kv_start, ws)
     out = ops.paged_decode(q.to(DEV).view(b, hq * 128), kc.to(DEV), vc.to(DEV), kv_indices, b, ws, 128 ** -0.5)
     torch.cuda.synchronize()
-    attn_close(out.view(b, hq, 128), ref)
+    attn_close(out.view(b, hq, 128), ref, p_bf16_vmax=decode_p_rounding(hq, hkv, vc))
     return ws
 
 
@@ -209,29 +221,58 @@ def test_decode_attention_small(ops, hq, hkv):
     _decode_case(ops, 10 + hq, [1, 2, 31, 32, 33, 127, 128, 129, 300], hq, hkv)
 
 
-def test_decode_attention_split_sequences(ops):
+@pytest.mark.parametrize("hq,hkv", DECODE_KERNEL_SHAPES)
+def test_decode_attention_split_sequences(ops, hq, hkv):
     # one long sequence alone: the plan must cut it into many chunks and the merge kernel must run
-    ws = _decode_case(ops, 21, [4000], 16, 8)
+    ws = _decode_case(ops, 21, [4000], hq, hkv)
     assert int(ws.plan[0]) > 1
-    _decode_case(ops, 22, [3000, 5, 700, 1], 16, 8, strided_table=True)
+    _decode_case(ops, 22, [3000, 5, 700, 1], hq, hkv, strided_table=True)
 
 
-def test_decode_attention_bench_like_batch(ops):
+@pytest.mark.parametrize("hq,hkv", DECODE_KERNEL_SHAPES)
+def test_decode_attention_bench_like_batch(ops, hq, hkv):
     rng = np.random.default_rng(5)
     lens = rng.integers(107, 1100, size=123).tolist()
-    _decode_case(ops, 23, lens, 16, 8)
+    _decode_case(ops, 23, lens, hq, hkv)
 
 
-def test_decode_zero_length_row_gives_zeros(ops):
+@pytest.mark.parametrize("hq,hkv", DECODE_KERNEL_SHAPES)
+def test_decode_zero_length_row_gives_zeros(ops, hq, hkv):
     gen = torch.Generator().manual_seed(2)
-    kc, vc = _random_cache(gen, 64, 8)
-    q = torch.randn(2, 16 * 128, generator=gen).to(torch.bfloat16).to(DEV)
-    ws = ops.DecodeWorkspace(2, 16, 8, DEV)
+    kc, vc = _random_cache(gen, 64, hkv)
+    q = torch.randn(2, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    ws = ops.DecodeWorkspace(2, hq, hkv, DEV)
     kv_len = torch.tensor([0, 3], dtype=torch.int32, device=DEV)
     kv_start = torch.tensor([0, 2], dtype=torch.int64, device=DEV)
     ops.decode_plan(kv_len, kv_start, ws)
     out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.arange(8, dtype=torch.int32, device=DEV), 2, ws, 0.1)
     assert not out[0].any() and out[1].any()
+
+
+def test_matrix_core_decode_kernel_at_every_head_ratio():
+    """NVX_DEC_RING=1 sends every head ratio to the LDS-ring + MFMA decode kernel (by default only ratios >= 8 go
+    there); the switch is read once per process, so the check runs in a process of its own: plain and raw-projection
+    entry points against the oracle for ratios 1, 2, 4, 8, with split sequences, ragged lengths and a 2-D table."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_kernels as t
+from nano_vllm_x_amd import _lib, ops
+_lib.load()
+for hq, hkv in [(2, 2), (4, 2), (16, 4), (16, 2), (64, 8), (4, 1)]:
+    t.decode_p_rounding = lambda hq, hkv, vc: float(vc.float().abs().max())     # every ratio rounds P to bf16 here
+    t._decode_case(ops, 50 + hq, [1, 2, 15, 16, 17, 31, 33, 128, 129, 300, 1000], hq, hkv)
+    t._decode_case(ops, 60 + hq, [3000, 5, 700, 1], hq, hkv, strided_table=True)
+    t.test_decode_attention_from_raw_qkv_matches_the_two_kernel_path(ops, hq, hkv)
+print("ring-ok")
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, NVX_DEC_RING="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ring-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 # -----------------------------------------------------------------------------------------------
@@ -554,7 +595,9 @@ def test_decode_attention_from_raw_qkv_matches_the_two_kernel_path(ops, hq, hkv)
     got = ops.paged_decode_qkv(qkv, pos, table, qw, kw, 1e-6, kc2, vc2, idx, b, ws2, 128 ** -0.5)
     torch.cuda.synchronize()
     assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
-    attn_close(got.view(b, hq, 128), want.view(b, hq, 128).float())
+    # (the matrix-core variant rounds P to bf16 against the running maximum of the moment, which the two paths reach in a
+    # different order: the new row is reduced last on the fused path, in its place in the slot list on the other)
+    attn_close(got.view(b, hq, 128), want.view(b, hq, 128).float(), p_bf16_vmax=decode_p_rounding(hq, hkv, vc))
 
 
 # -----------------------------------------------------------------------------------------------
@@ -599,14 +642,15 @@ def test_decode_full_size_is_invariant_to_slot_placement_and_linear_in_v(ops):
     assert ((af >= lo - 2 ** -6 * lo.abs() - 1e-3) & (af <= hi + 2 ** -6 * hi.abs() + 1e-3)).all()
 
 
-def test_decode_ragged_batch_with_empty_and_single_rows(ops):
+@pytest.mark.parametrize("hq,hkv", DECODE_KERNEL_SHAPES)
+def test_decode_ragged_batch_with_empty_and_single_rows(ops, hq, hkv):
     """Ragged lengths including 0 and 1, and a one-row batch, against the oracle."""
-    _decode_case(ops, 41, [1], 16, 8)
-    _decode_case(ops, 42, [3, 1, 257, 1, 64, 1000, 2], 16, 8)
+    _decode_case(ops, 41, [1], hq, hkv)
+    _decode_case(ops, 42, [3, 1, 257, 1, 64, 1000, 2, 15, 16, 17], hq, hkv)
     gen = torch.Generator().manual_seed(3)
-    kc, vc = _random_cache(gen, 64, 8)
-    ws = ops.DecodeWorkspace(3, 16, 8, DEV)
-    q = torch.randn(3, 16 * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    kc, vc = _random_cache(gen, 64, hkv)
+    ws = ops.DecodeWorkspace(3, hq, hkv, DEV)
+    q = torch.randn(3, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
     ops.decode_plan(torch.tensor([0, 0, 0], dtype=torch.int32, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV), ws)
     out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 3, ws, 0.1)
     assert not out.any(), "sequences with no keys must produce zeros"
@@ -679,11 +723,12 @@ def test_sampler_edge_cases(ops):
     assert torch.equal(draws, again) and not torch.equal(draws, other)
 
 
-def test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops):
+@pytest.mark.parametrize("hq,hkv", DECODE_KERNEL_SHAPES)
+def test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops, hq, hkv):
     from oracle.attention_oracle import paged_attention_oracle
 
     gen = torch.Generator().manual_seed(6)
-    hq, hkv, slots = 16, 8, 256
+    slots = 256
     kc, vc = _random_cache(gen, slots, hkv)
     kc = kc * 40            # q.k * scale reaches the hundreds: exp2 of the raw score would overflow
     q = (torch.randn(2, hq, 128, generator=gen) * 4).to(torch.bfloat16)
@@ -701,7 +746,7 @@ def test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops):
     ref_idx = torch.cat([kept0, valid[1]]).numpy()
     ref = paged_attention_oracle(q.float(), kc, vc, np.arange(3), np.array([0, kept0.numel(), kept0.numel() + 9]), ref_idx, 128 ** -0.5)
     assert torch.isfinite(out.float()).all()
-    attn_close(out, ref)
+    attn_close(out, ref, p_bf16_vmax=decode_p_rounding(hq, hkv, vc))
 
 
 def test_norm_and_rope_edge_rows(ops):

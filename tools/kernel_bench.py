@@ -61,9 +61,12 @@ def timed(fn, reps, graph=True):
 
 def cmd_decode(args):
     global HQ, HKV
+    if args.heads:
+        HQ, HKV = (int(x) for x in args.heads.split(","))
     prompts, max_tokens = bench.workload(256)
     slots = 200_000
     batches, n_dec, kv_rows = bench.decode_batches_of_workload(prompts, max_tokens, slots, 256, 4096, args.every)
+    layers = LAYERS if HKV >= 8 else 28 * 8 // HKV        # keep the pool larger than the Infinity Cache at few kv heads
     if args.hkv1:
         # same bytes, but every (sequence, kv head) becomes its own sequence of contiguous 256-byte rows:
         # isolates what the 2 KB row stride / partial-row reads cost
@@ -75,8 +78,8 @@ def cmd_decode(args):
             nb.append((lens8, flat8))
         batches = nb
         slots = 1_600_000
-    kc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
-    vc = torch.randn(LAYERS, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    kc = torch.randn(layers, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(layers, slots, HKV, 128, device=DEV, dtype=torch.bfloat16)
     ws = ops.DecodeWorkspace(2048 if args.hkv1 else 256, HQ, HKV, DEV)
     tot_b = tot_t = 0.0
     rows_out = []
@@ -99,13 +102,13 @@ def cmd_decode(args):
 
             def run():
                 ops.paged_decode_qkv(qkv, pos, table, nw, nw, 1e-6, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
-                layer[0] = (layer[0] + 1) % LAYERS
+                layer[0] = (layer[0] + 1) % layers
         else:
             ops.decode_plan(kv_len, kv_start, ws)
 
             def run():
                 ops.paged_decode(q, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
-                layer[0] = (layer[0] + 1) % LAYERS
+                layer[0] = (layer[0] + 1) % layers
 
         t = timed(run, args.reps)
         rows = int(lens.sum())
@@ -117,7 +120,7 @@ def cmd_decode(args):
     print("step  B  kv_rows  us  GB/s  items chunk")
     for r in rows_out:
         print(*r)
-    print(json.dumps({"kernel": "paged_decode(+merge)", "batches": len(batches), "avg_us": round(tot_t / len(batches) * 1e6, 2),
+    print(json.dumps({"kernel": "paged_decode(+merge)", "heads": [HQ, HKV], "batches": len(batches), "avg_us": round(tot_t / len(batches) * 1e6, 2),
                       "GBps": round(tot_b / tot_t / 1e9, 1), "frac_of_8TBps": round(tot_b / tot_t / 8e12, 4)}))
 
 
