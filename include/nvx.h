@@ -141,7 +141,9 @@ int nvx_rmsnorm_splitk(const float* partials, int n_splits, const void* residual
  * (n_slots, n_kv_heads, 128) bf16 of one layer; out (batch, n_q_heads, 128) bf16 contiguous.
  * softmax(q.k * sm_scale) in fp32.  partial_ws: fp32 scratch for split sequences,
  * >= nvx_decode_partial_ws_floats() floats.  Rows with kv_len <= 0 produce zeros; slot ids outside
- * [0, n_slots) are treated as masked keys.
+ * [0, n_slots) are treated as masked keys.  Two kernels stand behind it: up to 4 query heads per kv head rows go
+ * pool -> registers and the products are fp32 vector arithmetic; from 8 (and at 4 over one or two kv heads) rows go
+ * pool -> LDS and the products run on MFMA with the probabilities rounded to bf16, as in the prefill kernel.
  *
  * nvx_paged_decode_qkv is the same attention fed with the raw fused projection of the step instead of
  * finished queries: qkv (batch, (n_q_heads + 2*n_kv_heads)*128) as in nvx_qknorm_rope_store.  The
