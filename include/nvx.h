@@ -38,8 +38,9 @@ typedef void* nvx_stream_t;
 /* The one definition of the ABI version: nvx_abi_version() returns it, and the Python binding
  * (nano_vllm_x_amd/_lib.py) reads this line and refuses a library built from another header.
  * Bump it whenever a signature below changes.
- *   2: nvx_decode_step_setup gained `prev_ids`. */
-#define NVX_ABI_VERSION 2
+ *   2: nvx_decode_step_setup gained `prev_ids`.
+ *   3: float16 entry points (`*_f16`) added. */
+#define NVX_ABI_VERSION 3
 
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
@@ -259,6 +260,49 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
                           int64_t* kv_start, int32_t* kv_len, int64_t* out_slots,
                           int64_t* positions, int64_t* input_ids, const int64_t* prev_ids,
                           nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * IEEE half (float16) builds of the entry points whose arithmetic depends on the 16-bit format.  The reference
+ * resolves the dtype from the checkpoint and defaults to float16 (nanovllmx/core/model_runner.py:14-23,38-39).
+ * Same arguments and semantics as the entry point without the suffix, with "16-bit floating point" meaning
+ * float16 for activations, weights, KV rows and outputs: conversions round to nearest even into float16 (the
+ * intermediate roundings of the eager float16 ops), q.k by v_dot2_f32_f16, the MFMA products in their f16 forms.
+ * Built from the same sources as the bfloat16 entry points (compiled with -DNVX_F16).  The other entry points --
+ * KV scatter, the plans and workspace sizes, block table, the sampler (fp32 logits) -- serve both formats;
+ * nvx_paged_decode_noalloc exists for bfloat16 only. */
+int nvx_rmsnorm_f16(const void* x, int64_t x_row_stride, const void* residual, const void* weight,
+                int weight_is_f32, void* y, void* residual_out, int64_t rows, int64_t hidden,
+                float eps, nvx_stream_t stream);
+int nvx_rope_f16(const int64_t* positions, const float* cos_sin, int64_t max_pos,
+             const void* q, int64_t q_row_stride, const void* k, int64_t k_row_stride,
+             void* q_out, void* k_out, int64_t n_tokens, int n_q_heads, int n_kv_heads,
+             nvx_stream_t stream);
+int nvx_qknorm_rope_store_f16(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+                          const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
+                          const void* k_norm_weight, float eps, const int64_t* slots,
+                          void* q_out, void* k_cache, void* v_cache, int64_t n_slots,
+                          int64_t n_tokens, int n_q_heads, int n_kv_heads, nvx_stream_t stream);
+int nvx_silu_mul_f16(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream);
+int nvx_linear_decode_f16(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m,
+                      int64_t n, int64_t k, int mode, int k_splits, nvx_stream_t stream);
+int nvx_rmsnorm_splitk_f16(const float* partials, int n_splits, const void* residual, const void* weight,
+                       void* y, void* residual_out, int64_t rows, int64_t hidden, float eps,
+                       nvx_stream_t stream);
+int nvx_paged_decode_f16(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                     int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws,
+                     float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                     float sm_scale, nvx_stream_t stream);
+int nvx_paged_decode_qkv_f16(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+                         const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
+                         const void* k_norm_weight, float eps, void* k_cache, void* v_cache,
+                         int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws,
+                         float* partial_ws, void* out, int64_t batch, int n_q_heads, int n_kv_heads,
+                         float sm_scale, nvx_stream_t stream);
+int nvx_paged_prefill_f16(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                      int64_t n_slots, const int32_t* qo_indptr, const int32_t* kv_indptr,
+                      const int32_t* kv_indices, const int32_t* plan_ws, void* out,
+                      int64_t n_tokens, int64_t batch, int n_q_heads, int n_kv_heads,
+                      float sm_scale, nvx_stream_t stream);
 
 #ifdef __cplusplus
 }

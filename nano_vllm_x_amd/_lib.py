@@ -67,6 +67,13 @@ class NvxLibraryError(RuntimeError):
     pass
 
 
+# entry points that also exist as `<name>_f16` (IEEE half build of the same source, same signature)
+F16_ENTRY_POINTS = ("nvx_rmsnorm", "nvx_rope", "nvx_qknorm_rope_store", "nvx_silu_mul", "nvx_linear_decode", "nvx_rmsnorm_splitk",
+                    "nvx_paged_decode", "nvx_paged_decode_qkv", "nvx_paged_prefill")
+for _name in F16_ENTRY_POINTS:
+    SIGNATURES[_name + "_f16"] = SIGNATURES[_name]
+
+
 def load():
     """Load the HIP library once; raise loudly when it is absent (no fallback path exists)."""
     global _lib

@@ -68,14 +68,13 @@ class ModelRunner:
     def load_model(self, state_dict_iter=None):
         self.hf_config = self._config_override or load_config(self.model_path)
         cfg = self.hf_config
-        # The kernels compute in bfloat16.  A float16 or float32 checkpoint (the reference resolves the dtype from the
-        # checkpoint and defaults to float16, model_runner.py:14-23,38-39) is served in bfloat16 as well: same exponent
-        # range as float32, three mantissa bits fewer than float16; its tensors are converted as they are loaded.
+        # The kernels are built for bfloat16 and for float16 (the reference resolves the dtype from the checkpoint and
+        # defaults to float16, model_runner.py:14-23,38-39); a float32 checkpoint is served in bfloat16 (same exponent
+        # range), its tensors converted as they are loaded.
         self.checkpoint_dtype = _DTYPES[cfg.torch_dtype]
-        self.dtype = torch.bfloat16
-        if self.checkpoint_dtype != torch.bfloat16 and self.rank == 0:
-            print(f"[nano_vllm_x_amd] checkpoint dtype {cfg.torch_dtype}: weights are converted to bfloat16, the dtype the HIP "
-                  "kernels compute in", file=sys.stderr, flush=True)
+        self.dtype = self.checkpoint_dtype if self.checkpoint_dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+        if self.checkpoint_dtype != self.dtype and self.rank == 0:
+            print(f"[nano_vllm_x_amd] checkpoint dtype {cfg.torch_dtype}: weights are converted to bfloat16", file=sys.stderr, flush=True)
         self.num_heads, self.num_kv_heads, self.head_dim = get_model_config_per_gpu(cfg, self.tp_size)
         prev = torch.get_default_dtype()
         torch.set_default_dtype(self.dtype)

@@ -22,6 +22,9 @@
 #include <mutex>
 #include <stdlib.h>
 
+namespace NVX_NS {
+
+
 #define DEC_TARGET_UNITS 2048   // work units (chunk x kv head) the plan aims for
 #define DEC_MIN_CHUNK 128       // tokens
 #define DEC_MAX_CHUNK (1 << 24) // tokens: "do not split"
@@ -33,6 +36,7 @@ static inline int64_t dec_max_items(int64_t max_batch, int n_kv_heads) {
     return max_batch + 2048 / (n_kv_heads > 0 ? n_kv_heads : 1) + 8;
 }
 
+#ifndef NVX_F16   // independent of the 16-bit format: defined by the bfloat16 build only
 extern "C" int64_t nvx_decode_plan_ws_ints(int64_t max_batch, int n_kv_heads) {
     return 8 + DEC_REC_INTS * dec_max_items(max_batch, n_kv_heads) + 2 * max_batch;
 }
@@ -40,6 +44,8 @@ extern "C" int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads
     return dec_max_items(max_batch, n_kv_heads) * n_q_heads * DEC_PART_STRIDE;
 }
 
+#endif
+#ifndef NVX_F16   // independent of the 16-bit format: defined by the bfloat16 build only
 // plan_ws layout (int32): [0] n_items, [1] chunk, [2] batch, [3] max_items, [4..7] reserved,
 //   records[max_items][8], seq_info[batch][2] = (first item, number of chunks) of every sequence
 __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __restrict__ kv_len,
@@ -122,6 +128,7 @@ extern "C" int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, c
     return nvx_check_launch("nvx_decode_plan");
 }
 
+#endif
 // ---------------------------------------------------------------------------------------------
 // One wave's tile in registers: TPQ tokens per quarter-wave, K and V piece of each.
 template <int TPQ>
@@ -174,7 +181,7 @@ __device__ __forceinline__ void dec_compute(const DecTile<TPQ>& t, const nvx_u32
             for (int w = 0; w < 4; ++w) {
                 // copies first: __builtin_bit_cast straight from a vector-element lvalue reads element 0
                 const unsigned qw = qv[g][w], kw = t.k[u][w];
-                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nvx_bf16x2, qw), __builtin_bit_cast(nvx_bf16x2, kw), d, false);
+                d = dot2_h16(qw, kw, d);
             }
             d = quarter_sum(d);
             s[u][g] = ok ? d * scale_log2 : -INFINITY;
@@ -199,8 +206,8 @@ __device__ __forceinline__ void dec_compute(const DecTile<TPQ>& t, const nvx_u32
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const unsigned vw = ok ? t.v[u][w] : 0u;   // p = 0 times a stale NaN would still be NaN
-                acc[g][2 * w] += p * bf16lo_to_f32(vw);
-                acc[g][2 * w + 1] += p * bf16hi_to_f32(vw);
+                acc[g][2 * w] += p * h16lo_to_f32(vw);
+                acc[g][2 * w + 1] += p * h16hi_to_f32(vw);
             }
         }
     }
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const unsigned qw = qv[g][w], kw = k_new[w];
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nvx_bf16x2, qw), __builtin_bit_cast(nvx_bf16x2, kw), d, false);
+                    d = dot2_h16(qw, kw, d);
                 }
                 d = quarter_sum(d);
                 const float sc = mine ? d * scale_log2 : -INFINITY;
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const unsigned vw = mine ? (unsigned)v_new[w] : 0u;
-                    acc[g][2 * w] = acc[g][2 * w] * alpha + pr * bf16lo_to_f32(vw);
-                    acc[g][2 * w + 1] = acc[g][2 * w + 1] * alpha + pr * bf16hi_to_f32(vw);
+                    acc[g][2 * w] = acc[g][2 * w] * alpha + pr * h16lo_to_f32(vw);
+                    acc[g][2 * w + 1] = acc[g][2 * w + 1] * alpha + pr * h16hi_to_f32(vw);
                 }
             }
         }
@@ -409,8 +416,8 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
             if (nch == 1) {
                 const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
                 uint16_t* dst = out + ((int64_t)b * hq_total + hq) * 128 + pc * 8;
-                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv),
-                                                            pack_bf16x2(o[4] * inv, o[5] * inv), pack_bf16x2(o[6] * inv, o[7] * inv));
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_h16x2(o[0] * inv, o[1] * inv), pack_h16x2(o[2] * inv, o[3] * inv),
+                                                            pack_h16x2(o[4] * inv, o[5] * inv), pack_h16x2(o[6] * inv, o[7] * inv));
             } else {
                 float* dst = partial + ((int64_t)item * hq_total + hq) * DEC_PART_STRIDE;
                 *reinterpret_cast<float4*>(dst + pc * 8) = make_float4(o[0], o[1], o[2], o[3]);
@@ -482,7 +489,7 @@ __device__ __forceinline__ dec_s16x4 dec_lds_read_tr(unsigned addr) {
 typedef __attribute__((address_space(3))) nvx_u32x4 dec_lds_w4;
 __device__ __forceinline__ void dec_lds_write16(unsigned addr, nvx_u32x4 v) { *reinterpret_cast<dec_lds_w4*>((uintptr_t)addr) = v; }
 
-#ifdef DEC_STAMPS
+#if defined(DEC_STAMPS) && !defined(NVX_F16)
 // Build-time instrumentation (tools/build_variant.sh ... "-DDEC_STAMPS"): shader-clock stamps of the four waves of
 // workgroups 0..15 at four points of their first 16 stages, read back with nvx_debug_dec_stamps.  Never in the shipped library.
 __device__ unsigned long long dec_stamps[16 * 4 * 16 * 4];
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const nvx_u32x4 a = dec_lds_read16(base + k_lane + (((4 * ks + quarter) ^ l16) << 4));
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nvx_bf16x8, a), __builtin_bit_cast(nvx_bf16x8, qb[ks]), sacc, 0, 0, 0);
+                sacc = mfma_16x16x32_h16(a, qb[ks], sacc);
             }
             const unsigned mine4 = (okm >> (4 * quarter)) & 15u;   // tokens 4q .. 4q+3
             float sv[4];
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
             float p[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sv[r] - mref); l_run += p[r]; }
-            const uint32_t p01 = pack_bf16x2(p[0], p[1]), p23 = pack_bf16x2(p[2], p[3]);
+            const uint32_t p01 = pack_h16x2(p[0], p[1]), p23 = pack_h16x2(p[2], p[3]);
             const dec_s16x4 pb = __builtin_bit_cast(dec_s16x4, make_uint2(p01, p23));
             // value rows of tokens that are not keys may hold anything (0 x NaN = NaN): cleared in the operand
             const uint32_t vm01 = ((mine4 & 1u) ? 0xffffu : 0u) | ((mine4 & 2u) ? 0xffff0000u : 0u);
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
                 const dec_s16x4 vt = dec_lds_read_tr(base + v_lane + (((2 * blk + v_pc) ^ v_sw) << 4));
                 uint2 vw = __builtin_bit_cast(uint2, vt);
                 vw.x &= vm01; vw.y &= vm23;
-                o_acc[blk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(dec_s16x4, vw), pb, o_acc[blk], 0, 0, 0);
+                o_acc[blk] = mfma_16x16x16_h16(__builtin_bit_cast(dec_s16x4, vw), pb, o_acc[blk]);
             }
         };
 
@@ -734,8 +741,8 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
             if (nch == 1) {
                 const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
                 uint16_t* dst = out + ((int64_t)b * hq_total + hq) * 128 + pc * 8;
-                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv),
-                                                            pack_bf16x2(o[4] * inv, o[5] * inv), pack_bf16x2(o[6] * inv, o[7] * inv));
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pack_h16x2(o[0] * inv, o[1] * inv), pack_h16x2(o[2] * inv, o[3] * inv),
+                                                            pack_h16x2(o[4] * inv, o[5] * inv), pack_h16x2(o[6] * inv, o[7] * inv));
             } else {
                 float* dst = partial + ((int64_t)item * hq_total + hq) * DEC_PART_STRIDE;
                 *reinterpret_cast<float4*>(dst + pc * 8) = make_float4(o[0], o[1], o[2], o[3]);
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const int32_t* __rest
             mall = mnew;
         }
     }
-    out[((int64_t)b * hq_total + hq) * 128 + d] = f32_to_bf16bits(lsum > 0.f ? o / lsum : 0.f);
+    out[((int64_t)b * hq_total + hq) * 128 + d] = f32_to_h16bits(lsum > 0.f ? o / lsum : 0.f);
 }
 
 static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache, int64_t n_slots,
@@ -859,7 +866,7 @@ static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, 
     return nvx_check_launch(who);
 }
 
-extern "C" int nvx_paged_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+extern "C" int NVX_ENTRY(nvx_paged_decode)(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
                                 int64_t n_slots, const int32_t* kv_indices, const int32_t* plan_ws, float* partial_ws,
                                 void* out, int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale,
                                 nvx_stream_t stream) {
@@ -867,6 +874,7 @@ extern "C" int nvx_paged_decode(const void* q, int64_t q_row_stride, const void*
                       n_kv_heads, sm_scale, nullptr, n_q_heads * 128, "nvx_paged_decode", stream);
 }
 
+#ifndef NVX_F16   // the entry point that allocates nothing exists for bfloat16 only (one built-in array per library)
 // ---------------------------------------------------------------------------------------------
 // Entry point for callers that cannot allocate: plan, attention and merge out of one file-scope device
 // array instead of caller-provided workspaces.  Each GPU the library runs on holds its own copy of the
@@ -929,7 +937,9 @@ extern "C" int nvx_paged_decode_noalloc(const void* q, int64_t q_row_stride, con
                       n_kv_heads, sm_scale, nullptr, n_q_heads * 128, who, stream);
 }
 
-extern "C" int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+#endif
+
+extern "C" int NVX_ENTRY(nvx_paged_decode_qkv)(const void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
                                     int64_t max_pos, const void* q_norm_weight, const void* k_norm_weight, float eps,
                                     void* k_cache, void* v_cache, int64_t n_slots, const int32_t* kv_indices,
                                     const int32_t* plan_ws, float* partial_ws, void* out, int64_t batch, int n_q_heads,
@@ -942,3 +952,5 @@ extern "C" int nvx_paged_decode_qkv(const void* qkv, int64_t qkv_row_stride, con
     return dec_launch(qkv, qkv_row_stride, k_cache, v_cache, n_slots, kv_indices, plan_ws, partial_ws, out, batch, n_q_heads,
                       n_kv_heads, sm_scale, &fx, (n_q_heads + 2 * n_kv_heads) * 128, "nvx_paged_decode_qkv", stream);
 }
+
+}  // namespace NVX_NS

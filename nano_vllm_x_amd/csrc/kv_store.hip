@@ -1,6 +1,8 @@
 // KV scatter and device-resident block-table maintenance (integer / byte work, HBM-bound).
 #include "nvx_dev.h"
 
+namespace NVX_NS {
+
 // One 16-byte chunk per thread.  chunk id -> (token, K|V, chunk within row).  Consecutive
 // lanes copy consecutive 16-B chunks of one row, so both the gather from the (strided) source
 // and the scatter into the slot row are fully coalesced 1-KiB wave accesses.
@@ -118,3 +120,5 @@ extern "C" int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_
                        positions, input_ids, prev_ids);
     return nvx_check_launch("nvx_decode_step_setup");
 }
+
+}  // namespace NVX_NS

@@ -16,11 +16,15 @@
 //     the RMSNorm kernel that follows sums (nvx_rmsnorm_splitk).
 #include "nvx_dev.h"
 
+#include <stdlib.h>
+
+namespace NVX_NS {
+
 #define LIN_THREADS 512
 #define LIN_WAVES 8
 
 __device__ __forceinline__ nvx_f32x4 mfma16(nvx_u32x4 a, nvx_u32x4 b, nvx_f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nvx_bf16x8, a), __builtin_bit_cast(nvx_bf16x8, b), c, 0, 0, 0);
+    return mfma_16x16x32_h16(a, b, c);
 }
 
 // LDS slot (16 bytes each) of the A fragment piece: k-step j, lane quad q (k offset 8q), W row r.
@@ -144,18 +148,18 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
 #pragma unroll
             for (int h = 0; h < HALVES; ++h) {
                 uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_rows + col + h * 16;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[h][0], acc[h][1]), pack_bf16x2(acc[h][2], acc[h][3]));
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_h16x2(acc[h][0], acc[h][1]), pack_h16x2(acc[h][2], acc[h][3]));
             }
         } else if (MODE == 1) {
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gate = round_bf16(acc[0][r]), up = round_bf16(acc[HALVES - 1][r]);
-                const float sg = round_bf16(gate / (1.0f + __expf(-gate)));
+                const float gate = round_h16(acc[0][r]), up = round_h16(acc[HALVES - 1][r]);
+                const float sg = round_h16(gate / (1.0f + __expf(-gate)));
                 o[r] = sg * up;
             }
             uint16_t* dst = reinterpret_cast<uint16_t*>(y) + (int64_t)row * n_out + col;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3]));
         } else {
 #pragma unroll
             for (int h = 0; h < HALVES; ++h) {
@@ -274,16 +278,15 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_gateup_wide_kernel(
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float gate = round_bf16(acc[h][r]), up = round_bf16(acc[2 + h][r]);
-            const float sg = round_bf16(gate / (1.0f + __expf(-gate)));
+            const float gate = round_h16(acc[h][r]), up = round_h16(acc[2 + h][r]);
+            const float sg = round_h16(gate / (1.0f + __expf(-gate)));
             o[r] = sg * up;
         }
         uint16_t* dst = y + (int64_t)row * n_out + n0 + h * 16 + quad * 4;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3]));
     }
 }
 
-#include <stdlib.h>
 // rows above which the activations go through the LDS staging area (NVX_LIN_STAGED_MIN overrides: tuning)
 static int lin_staged_min_rows() {
     static int v = -1;
@@ -308,6 +311,7 @@ static int lin_gateup_wide_min_rows() { static int v = -1; if (v < 0) v = lin_en
 
 static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
 
+#ifndef NVX_F16   // independent of the 16-bit format: defined by the bfloat16 build only
 extern "C" int nvx_linear_decode_splits(int64_t n, int64_t k) {
     // smallest split whose K slice is one of the built sizes, preferring >= 256 workgroups; 0 = none
     int best = 0;
@@ -318,8 +322,9 @@ extern "C" int nvx_linear_decode_splits(int64_t n, int64_t k) {
     }
     return best;
 }
+#endif
 
-extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m, int64_t n, int64_t k,
+extern "C" int NVX_ENTRY(nvx_linear_decode)(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m, int64_t n, int64_t k,
                                  int mode, int k_splits, nvx_stream_t stream) {
     NVX_REQUIRE(x && w && y, NVX_EINVAL, "nvx_linear_decode: null pointer");
     NVX_REQUIRE(m > 0 && m <= 256, NVX_EUNSUPPORTED, "nvx_linear_decode: 1..256 rows (got %lld); larger batches are a library GEMM", (long long)m);
@@ -355,3 +360,5 @@ extern "C" int nvx_linear_decode(const void* x, int64_t x_row_stride, const void
 #undef NVX_LIN
     return nvx_check_launch("nvx_linear_decode");
 }
+
+}  // namespace NVX_NS

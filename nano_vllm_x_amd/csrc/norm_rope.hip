@@ -4,6 +4,8 @@
 #include "nvx_dev.h"
 #include "rope_dev.h"
 
+namespace NVX_NS {
+
 // ---------------------------------------------------------------------------------------------
 // RMSNorm: one wave per row, the row stays in registers between the two passes.
 // ---------------------------------------------------------------------------------------------
@@ -29,18 +31,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
                 uint32_t ow[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float lo = bf16lo_to_f32(aw[j]) + bf16lo_to_f32(rw[j]);
-                    const float hi = bf16hi_to_f32(aw[j]) + bf16hi_to_f32(rw[j]);
+                    const float lo = h16lo_to_f32(aw[j]) + h16lo_to_f32(rw[j]);
+                    const float hi = h16hi_to_f32(aw[j]) + h16hi_to_f32(rw[j]);
                     v[it][2 * j] = lo;
                     v[it][2 * j + 1] = hi;
-                    ow[j] = pack_bf16x2(lo, hi);
+                    ow[j] = pack_h16x2(lo, hi);
                 }
                 *reinterpret_cast<uint4*>(residual_out + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[it][2 * j] = bf16lo_to_f32(aw[j]);
-                    v[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                    v[it][2 * j] = h16lo_to_f32(aw[j]);
+                    v[it][2 * j + 1] = h16hi_to_f32(aw[j]);
                 }
             }
 #pragma unroll
@@ -63,12 +65,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
                 const uint4 wv = *reinterpret_cast<const uint4*>((const uint16_t*)weight + col);
                 const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { w[2 * j] = bf16lo_to_f32(ww[j]); w[2 * j + 1] = bf16hi_to_f32(ww[j]); }
+                for (int j = 0; j < 4; ++j) { w[2 * j] = h16lo_to_f32(ww[j]); w[2 * j + 1] = h16hi_to_f32(ww[j]); }
             }
             uint32_t ow[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                ow[j] = pack_bf16x2((v[it][2 * j] * inv) * w[2 * j], (v[it][2 * j + 1] * inv) * w[2 * j + 1]);
+                ow[j] = pack_h16x2((v[it][2 * j] * inv) * w[2 * j], (v[it][2 * j + 1] * inv) * w[2 * j + 1]);
             *reinterpret_cast<uint4*>(y + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
     }
@@ -85,7 +87,7 @@ static void launch_rmsnorm(const void* x, int64_t xs, const void* res, const voi
 #undef NVX_RMS
 }
 
-extern "C" int nvx_rmsnorm(const void* x, int64_t x_row_stride, const void* residual, const void* weight,
+extern "C" int NVX_ENTRY(nvx_rmsnorm)(const void* x, int64_t x_row_stride, const void* residual, const void* weight,
                            int weight_is_f32, void* y, void* residual_out, int64_t rows, int64_t hidden,
                            float eps, nvx_stream_t stream) {
     NVX_REQUIRE(rows >= 0 && hidden > 0, NVX_EINVAL, "nvx_rmsnorm: bad size");
@@ -151,14 +153,14 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
                 }
             }
             if (HAS_RES) {
-                v[it][0] = round_bf16(a[0]) + bf16lo_to_f32(r.x);
-                v[it][1] = round_bf16(a[1]) + bf16hi_to_f32(r.x);
-                v[it][2] = round_bf16(a[2]) + bf16lo_to_f32(r.y);
-                v[it][3] = round_bf16(a[3]) + bf16hi_to_f32(r.y);
+                v[it][0] = round_h16(a[0]) + h16lo_to_f32(r.x);
+                v[it][1] = round_h16(a[1]) + h16hi_to_f32(r.x);
+                v[it][2] = round_h16(a[2]) + h16lo_to_f32(r.y);
+                v[it][3] = round_h16(a[3]) + h16hi_to_f32(r.y);
                 *reinterpret_cast<uint2*>(residual_out + (int64_t)row * hidden + col) =
-                    make_uint2(pack_bf16x2(v[it][0], v[it][1]), pack_bf16x2(v[it][2], v[it][3]));
+                    make_uint2(pack_h16x2(v[it][0], v[it][1]), pack_h16x2(v[it][2], v[it][3]));
             } else {
-                v[it][0] = round_bf16(a[0]); v[it][1] = round_bf16(a[1]); v[it][2] = round_bf16(a[2]); v[it][3] = round_bf16(a[3]);
+                v[it][0] = round_h16(a[0]); v[it][1] = round_h16(a[1]); v[it][2] = round_h16(a[2]); v[it][3] = round_h16(a[3]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) ss += v[it][j] * v[it][j];
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
         const int col = it * 1024 + tid * 4;
         if (col < hidden) {
             *reinterpret_cast<uint2*>(y + (int64_t)row * hidden + col) =
-                make_uint2(pack_bf16x2((v[it][0] * inv) * bf16lo_to_f32(wv[it].x), (v[it][1] * inv) * bf16hi_to_f32(wv[it].x)),
-                           pack_bf16x2((v[it][2] * inv) * bf16lo_to_f32(wv[it].y), (v[it][3] * inv) * bf16hi_to_f32(wv[it].y)));
+                make_uint2(pack_h16x2((v[it][0] * inv) * h16lo_to_f32(wv[it].x), (v[it][1] * inv) * h16hi_to_f32(wv[it].x)),
+                           pack_h16x2((v[it][2] * inv) * h16lo_to_f32(wv[it].y), (v[it][3] * inv) * h16hi_to_f32(wv[it].y)));
         }
     }
 }
@@ -190,7 +192,7 @@ static void launch_rmsnorm_splitk(const float* p, int s, const void* res, const 
                             (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
 }
 
-extern "C" int nvx_rmsnorm_splitk(const float* partials, int n_splits, const void* residual, const void* weight, void* y,
+extern "C" int NVX_ENTRY(nvx_rmsnorm_splitk)(const float* partials, int n_splits, const void* residual, const void* weight, void* y,
                                   void* residual_out, int64_t rows, int64_t hidden, float eps, nvx_stream_t stream) {
     NVX_REQUIRE(rows >= 0 && rows <= 65536 && hidden > 0 && n_splits >= 1 && n_splits <= 64, NVX_EINVAL, "nvx_rmsnorm_splitk: bad size");
     if (rows == 0) return NVX_OK;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void rope_kernel(
     *reinterpret_cast<uint4*>(dst + 8 * l16) = o;
 }
 
-extern "C" int nvx_rope(const int64_t* positions, const float* cos_sin, int64_t max_pos, const void* q,
+extern "C" int NVX_ENTRY(nvx_rope)(const int64_t* positions, const float* cos_sin, int64_t max_pos, const void* q,
                         int64_t q_row_stride, const void* k, int64_t k_row_stride, void* q_out, void* k_out,
                         int64_t n_tokens, int n_q_heads, int n_kv_heads, nvx_stream_t stream) {
     NVX_REQUIRE(n_tokens >= 0 && n_q_heads >= 0 && n_kv_heads >= 0 && max_pos > 0, NVX_EINVAL, "nvx_rope: bad size");
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
         if (h[i] >= hq + hkv) {  // v: plain copy into the slot row
             if (!slot_ok) continue;
             uint16_t* dst = v_cache + (slot[i] * hkv + (h[i] - hq - hkv)) * 128;
-            *reinterpret_cast<uint2*>(dst + 4 * l16) = make_uint2(pack_bf16x2(x[i].a[0], x[i].a[1]), pack_bf16x2(x[i].a[2], x[i].a[3]));
-            *reinterpret_cast<uint2*>(dst + 64 + 4 * l16) = make_uint2(pack_bf16x2(x[i].b[0], x[i].b[1]), pack_bf16x2(x[i].b[2], x[i].b[3]));
+            *reinterpret_cast<uint2*>(dst + 4 * l16) = make_uint2(pack_h16x2(x[i].a[0], x[i].a[1]), pack_h16x2(x[i].a[2], x[i].a[3]));
+            *reinterpret_cast<uint2*>(dst + 64 + 4 * l16) = make_uint2(pack_h16x2(x[i].b[0], x[i].b[1]), pack_h16x2(x[i].b[2], x[i].b[3]));
             continue;
         }
         const bool is_q = h[i] < hq;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     }
 }
 
-extern "C" int nvx_qknorm_rope_store(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
+extern "C" int NVX_ENTRY(nvx_qknorm_rope_store)(const void* qkv, int64_t qkv_row_stride, const int64_t* positions,
                                      const float* cos_sin, int64_t max_pos, const void* q_norm_weight,
                                      const void* k_norm_weight, float eps, const int64_t* slots, void* q_out,
                                      void* k_cache, void* v_cache, int64_t n_slots, int64_t n_tokens,
@@ -326,7 +328,7 @@ extern "C" int nvx_qknorm_rope_store(const void* qkv, int64_t qkv_row_stride, co
 // ---------------------------------------------------------------------------------------------
 // SiluAndMul
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_bf16(float x) { return round_bf16(x / (1.0f + __expf(-x))); }
+__device__ __forceinline__ float silu_h16(float x) { return round_h16(x / (1.0f + __expf(-x))); }
 
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        int64_t rows, int d8) {
@@ -340,13 +342,13 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(silu_bf16(bf16lo_to_f32(gw[j])) * bf16lo_to_f32(uw[j]),
-                               silu_bf16(bf16hi_to_f32(gw[j])) * bf16hi_to_f32(uw[j]));
+            o[j] = pack_h16x2(silu_h16(h16lo_to_f32(gw[j])) * h16lo_to_f32(uw[j]),
+                               silu_h16(h16hi_to_f32(gw[j])) * h16hi_to_f32(uw[j]));
         *reinterpret_cast<uint4*>(y + id * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
-extern "C" int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream) {
+extern "C" int NVX_ENTRY(nvx_silu_mul)(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t stream) {
     NVX_REQUIRE(rows >= 0 && d > 0, NVX_EINVAL, "nvx_silu_mul: bad size");
     if (rows == 0) return NVX_OK;
     NVX_REQUIRE(x && y, NVX_EINVAL, "nvx_silu_mul: null pointer");
@@ -359,3 +361,5 @@ extern "C" int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx
                        (const uint16_t*)x, (uint16_t*)y, rows, (int)(d / 8));
     return nvx_check_launch("nvx_silu_mul");
 }
+
+}  // namespace NVX_NS

@@ -20,32 +20,89 @@ int nvx_check_launch(const char* what);
 
 static inline bool nvx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// ---- bf16 <-> f32 on raw bit patterns -----------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) __bf16 nvx_bf16x2;
-typedef __attribute__((ext_vector_type(8))) __bf16 nvx_bf16x8;
+// ---- the 16-bit floating-point format of activations, weights and KV rows --------------------------
+// Every kernel source is compiled twice: once as is (bfloat16, the format of the Qwen3 checkpoints) and once with
+// -DNVX_F16 (IEEE half, the reference's default dtype, nanovllmx/core/model_runner.py:14-23).  What differs between the
+// two builds is all here: the conversions, the packed dot product and the MFMA instructions.  Kernels and their static
+// state live in namespace NVX_NS so that the two builds of a source can be linked into one library, and an entry point
+// `name` of the bfloat16 build is `name_f16` in the other (NVX_ENTRY).
 typedef __attribute__((ext_vector_type(4))) float nvx_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int nvx_u32x4;   // a 16-byte move that stays in registers
 typedef __attribute__((ext_vector_type(16))) float nvx_f32x16;
+typedef __attribute__((ext_vector_type(4))) short nvx_s16x4;
 
-__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
-__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
-__device__ __forceinline__ float bf16bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+#ifdef NVX_F16
+#define NVX_NS nvx_f16
+#define NVX_ENTRY(name) name##_f16
+#define NVX_FORMAT_NAME "float16"
+typedef _Float16 nvx_h16;
+#else
+#define NVX_NS nvx_bf16
+#define NVX_ENTRY(name) name
+#define NVX_FORMAT_NAME "bfloat16"
+typedef __bf16 nvx_h16;
+#endif
+typedef __attribute__((ext_vector_type(2))) nvx_h16 nvx_h16x2;
+typedef __attribute__((ext_vector_type(4))) nvx_h16 nvx_h16x4;
+typedef __attribute__((ext_vector_type(8))) nvx_h16 nvx_h16x8;
 
-// Round-to-nearest-even f32 -> bf16 bits; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
-// and keeps NaNs NaN.
-__device__ __forceinline__ uint16_t f32_to_bf16bits(float f) {
-    __bf16 h = (__bf16)f;
+namespace NVX_NS {
+
+#ifdef NVX_F16
+__device__ __forceinline__ float h16lo_to_f32(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed & 0xffffu)); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
+__device__ __forceinline__ float h16bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+#else
+__device__ __forceinline__ float h16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ float h16bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+#endif
+
+// Round-to-nearest-even f32 -> 16-bit pattern; a plain cast lowers to the hardware conversion (v_cvt_pk_bf16_f32 /
+// v_cvt_f16_f32 on gfx950) and keeps NaNs NaN.
+__device__ __forceinline__ uint16_t f32_to_h16bits(float f) {
+    nvx_h16 h = (nvx_h16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
-// two conversions in one v_cvt_pk_bf16_f32 (round to nearest even, as the scalar conversion)
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+// two conversions, packed (round to nearest even, as the scalar conversion)
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nvx_h16x2));
 }
-// value of f after a round trip through bf16 (what eager bf16 arithmetic keeps of every result)
-__device__ __forceinline__ float round_bf16(float f) { return bf16bits_to_f32(f32_to_bf16bits(f)); }
+// value of f after a round trip through the 16-bit format (what eager arithmetic in that format keeps of every result)
+__device__ __forceinline__ float round_h16(float f) { return h16bits_to_f32(f32_to_h16bits(f)); }
+
+// c + a.x * b.x + a.y * b.y on packed pairs, fp32 accumulate (v_dot2c_f32_bf16 / v_dot2_f32_f16)
+__device__ __forceinline__ float dot2_h16(uint32_t a, uint32_t b, float c) {
+#ifdef NVX_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(nvx_h16x2, a), __builtin_bit_cast(nvx_h16x2, b), c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nvx_h16x2, a), __builtin_bit_cast(nvx_h16x2, b), c, false);
+#endif
+}
+// the MFMA shapes the kernels use, on raw 16-byte / 8-byte operand registers
+__device__ __forceinline__ nvx_f32x16 mfma_32x32x16_h16(nvx_h16x8 a, nvx_h16x8 b, nvx_f32x16 c) {
+#ifdef NVX_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ nvx_f32x4 mfma_16x16x32_h16(nvx_u32x4 a, nvx_u32x4 b, nvx_f32x4 c) {
+#ifdef NVX_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nvx_h16x8, a), __builtin_bit_cast(nvx_h16x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nvx_h16x8, a), __builtin_bit_cast(nvx_h16x8, b), c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ nvx_f32x4 mfma_16x16x16_h16(nvx_s16x4 a, nvx_s16x4 b, nvx_f32x4 c) {
+#ifdef NVX_F16
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(nvx_h16x4, a), __builtin_bit_cast(nvx_h16x4, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
+}
 
 // ---- wave-level reductions (wave = 64 lanes) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -72,3 +129,5 @@ __device__ __forceinline__ float quarter_sum(float v) {
     v += dpp_move<0x140>(v);   // row_mirror: lower 8 <-> upper 8
     return v;
 }
+
+}  // namespace NVX_NS

@@ -19,6 +19,9 @@
 
 #include <type_traits>
 
+namespace NVX_NS {
+
+
 #define PF_KVBLK 64
 #define PF_LOG2E 1.4426950408889634f
 
@@ -27,6 +30,7 @@ typedef __attribute__((address_space(3))) pf_s16x4 pf_lds_s16x4;
 
 // plan_ws (int32): three prefix tables, for 32, 64 and 128 query positions per workgroup:
 //   table t at ws + t*(batch+2): [0] = total blocks, [1 + b] = first block of sequence b, [1 + batch] = total
+#ifndef NVX_F16   // independent of the 16-bit format: defined by the bfloat16 build only
 extern "C" int64_t nvx_prefill_plan_ws_ints(int64_t batch) { return 3 * (batch + 2); }
 
 __global__ __launch_bounds__(1024) void prefill_plan_kernel(const int32_t* __restrict__ qo_indptr, int batch,
@@ -70,6 +74,7 @@ extern "C" int nvx_prefill_plan(const int32_t* qo_indptr, int64_t batch, int32_t
     return nvx_check_launch("nvx_prefill_plan");
 }
 
+#endif
 // Slot ids of a tile (64 keys) travel block table -> LDS one tile before the rows they name, as ONE
 // 256-byte copy issued by wave 0 (lane l fetches the id of key l).  No thread holds ids that are still
 // in flight: a load issued from inline assembly hands the compiler a register whose value arrives
@@ -137,7 +142,7 @@ __device__ __forceinline__ void pf_gather(unsigned ids, int krow0, unsigned n_sl
     for (int p = 0; p < PASSES; ++p) pf_gather_one(id[p], n_slots, kbase, vbase, row_bytes, k_dst + p * STEP, v_dst + p * STEP);
 }
 
-#ifdef PF_STAMPS
+#if defined(PF_STAMPS) && !defined(NVX_F16)
 // Build-time instrumentation (tools/build_variant.sh ... "-DPF_STAMPS"): shader-clock stamps of waves 0 and 3 of the
 // workgroups of query blocks 120 and 121 (kv head 0) at eight points of tiles 16..47, read back with nvx_debug_pf_stamps.
 // Never in the shipped library.
@@ -208,14 +213,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     const int n_tiles = (kmax + PF_KVBLK - 1) / PF_KVBLK;
 
     // Q^T fragments: 8 k-steps of 16 dims; lane holds dims 16*ks + 8*half .. +7 of its query row
-    nvx_bf16x8 qf[8];
+    nvx_h16x8 qf[8];
     {
         const uint16_t* qrow = q + (int64_t)(q0 + (q_ok ? qi : 0)) * q_stride + hq * 128 + half * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             uint4 t = *reinterpret_cast<const uint4*>(qrow + ks * 16);
             if (!q_ok) t = make_uint4(0, 0, 0, 0);
-            qf[ks] = __builtin_bit_cast(nvx_bf16x8, t);
+            qf[ks] = __builtin_bit_cast(nvx_h16x8, t);
         }
     }
 
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, kf[kb][ks]), qf[ks], st[kb], 0, 0, 0);
+                st[kb] = mfma_32x32x16_h16(__builtin_bit_cast(nvx_h16x8, kf[kb][ks]), qf[ks], st[kb]);
         // scheduling order for this region: the LDS reads, then the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 8 * NKB, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8 * NKB, 0);
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         read_group(0);
         read_group(1);
         __builtin_amdgcn_sched_barrier(0);
-        nvx_bf16x8 pf[NGRP];
+        nvx_h16x8 pf[NGRP];
         auto probabilities = [&](int gi) {   // P^T of 16 keys: 8 exponentials per lane
             const int kb = gi >> 1, s2 = gi & 1;
             uint32_t w[4];
@@ -377,9 +382,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
                 const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j], scale_log2, -mref));
                 const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][8 * s2 + 2 * j + 1], scale_log2, -mref));
                 l_run += p0 + p1;
-                w[j] = pack_bf16x2(p0, p1);
+                w[j] = pack_h16x2(p0, p1);
             }
-            pf[gi] = __builtin_bit_cast(nvx_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            pf[gi] = __builtin_bit_cast(nvx_h16x8, make_uint4(w[0], w[1], w[2], w[3]));
         };
         probabilities(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
         for (int gi = 0; gi < NGRP; ++gi) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nvx_bf16x8, vf[gi][d]), pf[gi], o_acc[d], 0, 0, 0);
+                o_acc[d] = mfma_32x32x16_h16(__builtin_bit_cast(nvx_h16x8, vf[gi][d]), pf[gi], o_acc[d]);
             if (gi + 1 < NGRP) probabilities(gi + 1);
             if (gi + 2 < NGRP) read_group(gi + 2);
             if (gi + 1 < NGRP) {
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int dim = d * 32 + 8 * r4 + 4 * half;
                 *reinterpret_cast<lds_u2*>((uintptr_t)(stage + l32 * ROW + dim * 2)) =
-                    u32x2{pack_bf16x2(o_acc[d][4 * r4] * inv, o_acc[d][4 * r4 + 1] * inv),
-                          pack_bf16x2(o_acc[d][4 * r4 + 2] * inv, o_acc[d][4 * r4 + 3] * inv)};
+                    u32x2{pack_h16x2(o_acc[d][4 * r4] * inv, o_acc[d][4 * r4 + 1] * inv),
+                          pack_h16x2(o_acc[d][4 * r4 + 2] * inv, o_acc[d][4 * r4 + 3] * inv)};
             }
         // a wave's LDS operations complete in order: no barrier between its writes and its reads
         const int rq = lane >> 4, pc = lane & 15;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     }
 }
 
-extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+extern "C" int NVX_ENTRY(nvx_paged_prefill)(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
                                  int64_t n_slots, const int32_t* qo_indptr, const int32_t* kv_indptr,
                                  const int32_t* kv_indices, const int32_t* plan_ws, void* out, int64_t n_tokens,
                                  int64_t batch, int n_q_heads, int n_kv_heads, float sm_scale, nvx_stream_t stream) {
@@ -492,3 +497,5 @@ extern "C" int nvx_paged_prefill(const void* q, int64_t q_row_stride, const void
 #undef NVX_PF
     return nvx_check_launch("nvx_paged_prefill");
 }
+
+}  // namespace NVX_NS

@@ -18,6 +18,8 @@
 // Random numbers: Philox4x32-10 keyed by `seed`, counter = (token/4, row, offset).
 #include "nvx_dev.h"
 
+namespace NVX_NS {
+
 #define SMP_THREADS 1024
 #define SMP_MAX_SPLIT 16
 
@@ -58,7 +60,7 @@ __device__ __forceinline__ unsigned long long pack_winner(float v, int idx) {
 template <bool F32>
 __device__ __forceinline__ float load_logit(const void* row, int64_t i) {
     if (F32) return reinterpret_cast<const float*>(row)[i];
-    return bf16bits_to_f32(reinterpret_cast<const uint16_t*>(row)[i]);
+    return h16bits_to_f32(reinterpret_cast<const uint16_t*>(row)[i]);
 }
 
 struct BlockScratch {
@@ -647,8 +649,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
             const uint32_t k0 = kw & 0xffffu, k1 = kw >> 16;
             if (__any(k0 >= k_key || k1 >= k_key)) {   // (with a small top-k nearly every wave skips the exponentials)
                 const uint32_t pr = pair_of_keys(kw);
-                const unsigned long long m0 = k0 >= k_key ? mass_fixed(bf16lo_to_f32(pr), c1, c2m) : 0u;
-                const unsigned long long m1 = k1 >= k_key ? mass_fixed(bf16hi_to_f32(pr), c1, c2m) : 0u;
+                const unsigned long long m0 = k0 >= k_key ? mass_fixed(h16lo_to_f32(pr), c1, c2m) : 0u;
+                const unsigned long long m1 = k1 >= k_key ? mass_fixed(h16hi_to_f32(pr), c1, c2m) : 0u;
                 atomicAdd(my64 + (k0 >> 8) * 16, m0);
                 atomicAdd(my64 + (k1 >> 8) * 16, m1);
             }
@@ -678,8 +680,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
             const bool t0 = k0 >= k_key && (k0 >> 8) == hi, t1 = k1 >= k_key && (k1 >> 8) == hi;
             if (__any(t0 || t1)) {
                 const uint32_t pr = pair_of_keys(kw);
-                const unsigned long long m0 = t0 ? mass_fixed(bf16lo_to_f32(pr), c1, c2m) : 0u;
-                const unsigned long long m1 = t1 ? mass_fixed(bf16hi_to_f32(pr), c1, c2m) : 0u;
+                const unsigned long long m0 = t0 ? mass_fixed(h16lo_to_f32(pr), c1, c2m) : 0u;
+                const unsigned long long m1 = t1 ? mass_fixed(h16hi_to_f32(pr), c1, c2m) : 0u;
                 atomicAdd(my64 + (k0 & 255u) * 16, m0);
                 atomicAdd(my64 + (k1 & 255u) * 16, m1);
             }
@@ -756,8 +758,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
         float zl = 0.f;
         each_pair([&](int i, uint32_t kw) {
             const uint32_t pr = pair_of_keys(kw);
-            if (kept_kp(kw & 0xffffu, i)) zl += __expf(bf16lo_to_f32(pr) / T - M);
-            if (kept_kp(kw >> 16, i + 1)) zl += __expf(bf16hi_to_f32(pr) / T - M);
+            if (kept_kp(kw & 0xffffu, i)) zl += __expf(h16lo_to_f32(pr) / T - M);
+            if (kept_kp(kw >> 16, i + 1)) zl += __expf(h16hi_to_f32(pr) / T - M);
         });
         Z2 = block_sum(zl, sc.blk);
         minp_thr = min_p * (1.0f / Z2);
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
         float zl = 0.f;
         each_pair([&](int i, uint32_t kw) {
             const uint32_t pr = pair_of_keys(kw);
-            const float l0 = bf16lo_to_f32(pr), l1 = bf16hi_to_f32(pr);
+            const float l0 = h16lo_to_f32(pr), l1 = h16hi_to_f32(pr);
             if (kept(kw & 0xffffu, l0, i)) zl += __expf(l0 / T - M);
             if (kept(kw >> 16, l1, i + 1)) zl += __expf(l1 / T - M);
         });
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
         float* prow = probs_out + (int64_t)row * vocab;
         each_pair([&](int i, uint32_t kw) {
             const uint32_t pr = pair_of_keys(kw);
-            const float l0 = bf16lo_to_f32(pr), l1 = bf16hi_to_f32(pr);
+            const float l0 = h16lo_to_f32(pr), l1 = h16hi_to_f32(pr);
             prow[i] = kept(kw & 0xffffu, l0, i) ? __expf(l0 / T - M) / Z3 : 0.0f;
             prow[i + 1] = kept(kw >> 16, l1, i + 1) ? __expf(l1 / T - M) / Z3 : 0.0f;
         });
@@ -797,8 +799,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
         bool a, b;
         if (min_p > 0.0f) {
             const uint32_t pr = pair_of_keys(kw);
-            a = kept(kw & 0xffffu, bf16lo_to_f32(pr), i);
-            b = kept(kw >> 16, bf16hi_to_f32(pr), i + 1);
+            a = kept(kw & 0xffffu, h16lo_to_f32(pr), i);
+            b = kept(kw >> 16, h16hi_to_f32(pr), i + 1);
         } else {
             a = kept_kp(kw & 0xffffu, i);
             b = kept_kp(kw >> 16, i + 1);
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
             const int pos = wd * 32 + __ffs((int)m) - 1;
             m &= m - 1;
             const int i = ((pos >> 3) * SMP_THREADS + tid) * 8 + (pos & 7);
-            const float l = bf16bits_to_f32(lrow[i]);
+            const float l = h16bits_to_f32(lrow[i]);
             if ((i & ~3) != gbase) {
                 gbase = i & ~3;
                 const uint4 r = philox4x32_10(make_uint4((uint32_t)(gbase >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)), key);
@@ -950,3 +952,5 @@ extern "C" int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t 
                                             (int)vocab, 0ull, 0ull, nullptr, probs_out, nullptr, 1);
     return nvx_check_launch("nvx_sampler_probs");
 }
+
+}  // namespace NVX_NS

@@ -33,6 +33,8 @@ class Sampler(nn.Module):
             top_ps = torch.ones(b, dtype=torch.float32, device=dev)
         if top_ks is None:
             top_ks = torch.full((b,), v, dtype=torch.int64, device=dev)
+        if logits.dtype == torch.float16:
+            logits = logits.float()   # the kernel reads bfloat16 or fp32 logits (the reference samples in fp32: sampler.py:37-38)
         if logits.stride(-1) != 1:
             logits = logits.contiguous()
         self.calls += 1

@@ -13,6 +13,13 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+H16 = (BF16, F16)   # the 16-bit formats the library is built for: the kernels of a call all run in the format of its activations
+
+
+def _fn(lib, name: str, dtype):
+    """Entry point `name` in the build for `dtype`: bfloat16 is the unsuffixed symbol, float16 `name_f16`."""
+    return getattr(lib, name + "_f16" if dtype == F16 else name)
 
 
 def _stream() -> int:
@@ -54,7 +61,7 @@ def store_kvcache(k, v, k_cache, v_cache, kv_indices):
 def rmsnorm(x, weight, eps, residual=None):
     """RMSNorm.forward (layernorm.py:17-36): returns y, or (y, new_residual) when residual is given."""
     _dev(x, weight, residual)
-    _need(x.dtype == BF16, "rmsnorm: bf16 activations only")
+    _need(x.dtype in H16, "rmsnorm: bfloat16 or float16 activations")
     hidden = x.shape[-1]
     if x.dim() == 2 and x.stride(1) == 1:
         x2 = x  # rows may be strided (a split view of a fused projection)
@@ -63,15 +70,15 @@ def rmsnorm(x, weight, eps, residual=None):
         x2 = x.view(-1, hidden)
     rows = x2.shape[0]
     _need(weight.numel() == hidden and weight.is_contiguous(), "rmsnorm: weight shape")
-    _need(weight.dtype in (BF16, torch.float32), "rmsnorm: weight must be bf16 or fp32")
-    y = torch.empty((rows, hidden), dtype=BF16, device=x.device)
+    _need(weight.dtype in (x.dtype, torch.float32), "rmsnorm: weight must have the activations' dtype or be fp32")
+    y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
     res_out = None
     if residual is not None:
-        _need(residual.dtype == BF16 and residual.shape == x.shape, "rmsnorm: residual shape/dtype")
+        _need(residual.dtype == x.dtype and residual.shape == x.shape, "rmsnorm: residual shape/dtype")
         residual = residual.contiguous()
-        res_out = torch.empty((rows, hidden), dtype=BF16, device=x.device)
+        res_out = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.nvx_rmsnorm(_ptr(x2), x2.stride(0), _ptr(residual), _ptr(weight), int(weight.dtype == torch.float32),
+    _lib.check(_fn(lib, "nvx_rmsnorm", x.dtype)(_ptr(x2), x2.stride(0), _ptr(residual), _ptr(weight), int(weight.dtype == torch.float32),
                                _ptr(y), _ptr(res_out), rows, hidden, float(eps), _stream()), "nvx_rmsnorm")
     y = y.view(x.shape)
     if residual is None:
@@ -84,16 +91,16 @@ def rope(positions, q, k, cos_sin_cache, head_size=128):
     _dev(positions, q, k, cos_sin_cache)
     _need(head_size == 128 and cos_sin_cache.shape[-1] == 128 and cos_sin_cache.dtype == torch.float32 and
           cos_sin_cache.is_contiguous(), "rope: needs an fp32 (max_pos, 128) table")
-    _need(q.dtype == BF16 and k.dtype == BF16, "rope: bf16 only")
+    _need(q.dtype in H16 and k.dtype == q.dtype, "rope: bfloat16 or float16, q and k alike")
     positions = positions.flatten()
     _need(positions.dtype == torch.int64 and positions.is_contiguous(), "rope: positions must be int64")
     t = positions.numel()
     q2, k2 = q.reshape(t, -1) if q.is_contiguous() else q.view(t, -1), k.reshape(t, -1) if k.is_contiguous() else k.view(t, -1)
     _need(q2.stride(1) == 1 and k2.stride(1) == 1 and q2.shape[1] % 128 == 0 and k2.shape[1] % 128 == 0, "rope: row layout")
-    q_out = torch.empty((t, q2.shape[1]), dtype=BF16, device=q.device)
-    k_out = torch.empty((t, k2.shape[1]), dtype=BF16, device=k.device)
+    q_out = torch.empty((t, q2.shape[1]), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((t, k2.shape[1]), dtype=k.dtype, device=k.device)
     lib = _lib.load()
-    _lib.check(lib.nvx_rope(_ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0], _ptr(q2), q2.stride(0), _ptr(k2),
+    _lib.check(_fn(lib, "nvx_rope", q.dtype)(_ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0], _ptr(q2), q2.stride(0), _ptr(k2),
                             k2.stride(0), _ptr(q_out), _ptr(k_out), t, q2.shape[1] // 128, k2.shape[1] // 128, _stream()),
                "nvx_rope")
     return q_out.view(q.shape), k_out.view(k.shape)
@@ -105,20 +112,20 @@ def qknorm_rope_store(qkv, positions, cos_sin_cache, q_norm_weight, k_norm_weigh
     _dev(qkv, positions, cos_sin_cache, q_norm_weight, k_norm_weight, slots, k_cache, v_cache)
     t = qkv.shape[0]
     width = (n_q_heads + 2 * n_kv_heads) * 128
-    _need(qkv.dim() == 2 and qkv.shape[1] == width and qkv.stride(1) == 1 and qkv.dtype == BF16, "qknorm_rope_store: qkv layout")
+    _need(qkv.dim() == 2 and qkv.shape[1] == width and qkv.stride(1) == 1 and qkv.dtype in H16, "qknorm_rope_store: qkv layout")
     _need(positions.dtype == torch.int64 and positions.numel() >= t and positions.is_contiguous(), "qknorm_rope_store: positions")
     _need(slots.dtype == torch.int64 and slots.numel() >= t and slots.is_contiguous(), "qknorm_rope_store: slots")
     _need(k_cache.shape[-2:] == (n_kv_heads, 128) and v_cache.shape == k_cache.shape and k_cache.is_contiguous() and
-          v_cache.is_contiguous() and k_cache.dtype == BF16, "qknorm_rope_store: cache layout")
-    _need(q_norm_weight.dtype == BF16 and k_norm_weight.dtype == BF16 and q_norm_weight.numel() == 128 and
+          v_cache.is_contiguous() and k_cache.dtype == qkv.dtype and v_cache.dtype == qkv.dtype, "qknorm_rope_store: cache layout")
+    _need(q_norm_weight.dtype == qkv.dtype and k_norm_weight.dtype == qkv.dtype and q_norm_weight.numel() == 128 and
           k_norm_weight.numel() == 128, "qknorm_rope_store: norm weights must be bf16 (128)")
     _need(cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[-1] == 128 and cos_sin_cache.is_contiguous(), "qknorm_rope_store: table")
     if q_out is None:
-        q_out = torch.empty((t, n_q_heads * 128), dtype=BF16, device=qkv.device)
+        q_out = torch.empty((t, n_q_heads * 128), dtype=qkv.dtype, device=qkv.device)
     else:
-        _need(q_out.shape == (t, n_q_heads * 128) and q_out.is_contiguous() and q_out.dtype == BF16, "qknorm_rope_store: q_out")
+        _need(q_out.shape == (t, n_q_heads * 128) and q_out.is_contiguous() and q_out.dtype == qkv.dtype, "qknorm_rope_store: q_out")
     lib = _lib.load()
-    _lib.check(lib.nvx_qknorm_rope_store(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
+    _lib.check(_fn(lib, "nvx_qknorm_rope_store", qkv.dtype)(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
                                          _ptr(q_norm_weight), _ptr(k_norm_weight), float(eps), _ptr(slots), _ptr(q_out),
                                          _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], t, n_q_heads, n_kv_heads, _stream()),
                "nvx_qknorm_rope_store")
@@ -133,14 +140,14 @@ def linear_decode(x, w, mode: int = 0, k_splits: int = 1, out=None):
     """x (m <= 256, k) bf16 times w (n, k)^T.  mode 0 -> bf16 (m, n); mode 1 -> SiluAndMul of the
     [gate; up] projection, bf16 (m, n/2); mode 2 -> fp32 partials (k_splits, m, n) for rmsnorm_splitk."""
     _dev(x, w, out)
-    _need(x.dim() == 2 and w.dim() == 2 and x.dtype == BF16 and w.dtype == BF16, "linear_decode: 2-D bf16 operands")
+    _need(x.dim() == 2 and w.dim() == 2 and x.dtype in H16 and w.dtype == x.dtype, "linear_decode: 2-D bfloat16 or float16 operands")
     _need(x.stride(1) == 1 and w.is_contiguous() and x.shape[1] == w.shape[1], "linear_decode: layouts")
     m, k = x.shape
     n = w.shape[0]
     if mode == 0:
-        shape, dtype = (m, n), BF16
+        shape, dtype = (m, n), x.dtype
     elif mode == 1:
-        shape, dtype = (m, n // 2), BF16
+        shape, dtype = (m, n // 2), x.dtype
     else:
         shape, dtype = (k_splits, m, n), torch.float32
     if out is None:
@@ -149,7 +156,7 @@ def linear_decode(x, w, mode: int = 0, k_splits: int = 1, out=None):
         _need(out.dtype == dtype and out.is_contiguous() and out.numel() >= shape[0] * shape[1] * (shape[2] if len(shape) == 3 else 1),
               "linear_decode: out")
     lib = _lib.load()
-    _lib.check(lib.nvx_linear_decode(_ptr(x), x.stride(0), _ptr(w), _ptr(out), m, n, k, mode, k_splits, _stream()), "nvx_linear_decode")
+    _lib.check(_fn(lib, "nvx_linear_decode", x.dtype)(_ptr(x), x.stride(0), _ptr(w), _ptr(out), m, n, k, mode, k_splits, _stream()), "nvx_linear_decode")
     return out
 
 
@@ -157,15 +164,15 @@ def rmsnorm_splitk(partials, weight, eps, residual=None):
     """RMSNorm over bf16(sum of fp32 partials (splits, rows, hidden)); returns y or (y, new_residual)."""
     _dev(partials, weight, residual)
     _need(partials.dim() == 3 and partials.dtype == torch.float32 and partials.is_contiguous(), "rmsnorm_splitk: partials")
-    _need(weight.dtype == BF16 and weight.is_contiguous(), "rmsnorm_splitk: bf16 weight")
+    _need(weight.dtype in H16 and weight.is_contiguous(), "rmsnorm_splitk: bfloat16 or float16 weight (it sets the output format)")
     s, rows, hidden = partials.shape
-    y = torch.empty((rows, hidden), dtype=BF16, device=partials.device)
+    y = torch.empty((rows, hidden), dtype=weight.dtype, device=partials.device)
     res_out = None
     if residual is not None:
-        _need(residual.dtype == BF16 and residual.is_contiguous() and residual.shape == (rows, hidden), "rmsnorm_splitk: residual")
+        _need(residual.dtype == weight.dtype and residual.is_contiguous() and residual.shape == (rows, hidden), "rmsnorm_splitk: residual")
         res_out = torch.empty_like(residual)
     lib = _lib.load()
-    _lib.check(lib.nvx_rmsnorm_splitk(_ptr(partials), s, _ptr(residual), _ptr(weight), _ptr(y), _ptr(res_out), rows, hidden,
+    _lib.check(_fn(lib, "nvx_rmsnorm_splitk", weight.dtype)(_ptr(partials), s, _ptr(residual), _ptr(weight), _ptr(y), _ptr(res_out), rows, hidden,
                                       float(eps), _stream()), "nvx_rmsnorm_splitk")
     return y if residual is None else (y, res_out)
 
@@ -173,15 +180,15 @@ def rmsnorm_splitk(partials, weight, eps, residual=None):
 def silu_mul(x, out=None):
     """SiluAndMul.forward (activation.py:15-18)."""
     _dev(x)
-    _need(x.dtype == BF16 and x.is_contiguous(), "silu_mul: contiguous bf16 only")
+    _need(x.dtype in H16 and x.is_contiguous(), "silu_mul: contiguous bfloat16 or float16")
     d = x.shape[-1] // 2
     rows = x.numel() // (2 * d)
     if out is None:
-        out = torch.empty(x.shape[:-1] + (d,), dtype=BF16, device=x.device)
+        out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
     else:
-        _need(out.is_contiguous() and out.numel() == rows * d and out.dtype == BF16, "silu_mul: out")
+        _need(out.is_contiguous() and out.numel() == rows * d and out.dtype == x.dtype, "silu_mul: out")
     lib = _lib.load()
-    _lib.check(lib.nvx_silu_mul(_ptr(x), _ptr(out), rows, d, _stream()), "nvx_silu_mul")
+    _lib.check(_fn(lib, "nvx_silu_mul", x.dtype)(_ptr(x), _ptr(out), rows, d, _stream()), "nvx_silu_mul")
     return out
 
 
@@ -238,21 +245,21 @@ def paged_decode_qkv(qkv, positions, cos_sin_cache, q_weight, k_weight, eps, k_c
     _dev(qkv, positions, cos_sin_cache, q_weight, k_weight, k_cache, v_cache, kv_indices)
     b = batch
     hq, hkv = ws.n_q_heads, ws.n_kv_heads
-    _need(qkv.dim() == 2 and qkv.shape[0] == b and qkv.shape[1] == (hq + 2 * hkv) * 128 and qkv.dtype == BF16 and qkv.stride(1) == 1,
+    _need(qkv.dim() == 2 and qkv.shape[0] == b and qkv.shape[1] == (hq + 2 * hkv) * 128 and qkv.dtype in H16 and qkv.stride(1) == 1,
           "paged_decode_qkv: qkv layout")
     _need(positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == b, "paged_decode_qkv: positions")
     _need(cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == 128,
           "paged_decode_qkv: cos/sin table")
-    _need(q_weight.dtype == BF16 and k_weight.dtype == BF16 and q_weight.numel() == 128 and k_weight.numel() == 128,
+    _need(q_weight.dtype == qkv.dtype and k_weight.dtype == qkv.dtype and q_weight.numel() == 128 and k_weight.numel() == 128,
           "paged_decode_qkv: norm weights")
-    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+    _need(k_cache.dtype == qkv.dtype and v_cache.dtype == qkv.dtype and k_cache.is_contiguous() and v_cache.is_contiguous() and
           tuple(k_cache.shape[-2:]) == (hkv, 128) and v_cache.shape == k_cache.shape, "paged_decode_qkv: cache layout")
     _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode_qkv: kv_indices must be int32")
     _need(0 < b <= ws.max_batch, "paged_decode_qkv: batch exceeds the workspace")
     if out is None:
-        out = torch.empty((b, hq * 128), dtype=BF16, device=qkv.device)
+        out = torch.empty((b, hq * 128), dtype=qkv.dtype, device=qkv.device)
     lib = _lib.load()
-    _lib.check(lib.nvx_paged_decode_qkv(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
+    _lib.check(_fn(lib, "nvx_paged_decode_qkv", qkv.dtype)(_ptr(qkv), qkv.stride(0), _ptr(positions), _ptr(cos_sin_cache), cos_sin_cache.shape[0],
                                         _ptr(q_weight), _ptr(k_weight), float(eps), _ptr(k_cache), _ptr(v_cache), k_cache.shape[-3],
                                         _ptr(kv_indices), _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv, float(sm_scale),
                                         _stream()), "nvx_paged_decode_qkv")
@@ -266,17 +273,17 @@ def paged_decode(q, k_cache, v_cache, kv_indices, batch: int, ws: DecodeWorkspac
     b = batch
     hq, hkv = ws.n_q_heads, ws.n_kv_heads
     q2 = q.view(b, hq * 128)
-    _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_decode: q layout")
-    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+    _need(q2.dtype in H16 and q2.stride(1) == 1, "paged_decode: q layout")
+    _need(k_cache.dtype == q2.dtype and v_cache.dtype == q2.dtype and k_cache.is_contiguous() and v_cache.is_contiguous() and
           tuple(k_cache.shape[-2:]) == (hkv, 128) and v_cache.shape == k_cache.shape, "paged_decode: cache layout")
     _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode: kv_indices must be int32")
     _need(0 < b <= ws.max_batch, "paged_decode: batch exceeds the workspace")
     if out is None:
-        out = torch.empty((b, hq * 128), dtype=BF16, device=q.device)
+        out = torch.empty((b, hq * 128), dtype=q2.dtype, device=q.device)
     else:
-        _need(out.is_contiguous() and out.numel() == b * hq * 128 and out.dtype == BF16, "paged_decode: out")
+        _need(out.is_contiguous() and out.numel() == b * hq * 128 and out.dtype == q2.dtype, "paged_decode: out")
     lib = _lib.load()
-    _lib.check(lib.nvx_paged_decode(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
+    _lib.check(_fn(lib, "nvx_paged_decode", q2.dtype)(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(kv_indices),
                                     _ptr(ws.plan), _ptr(ws.partial), _ptr(out), b, hq, hkv, float(sm_scale), _stream()),
                "nvx_paged_decode")
     return out
@@ -289,7 +296,7 @@ def paged_decode_noalloc(q, k_cache, v_cache, kv_indices, kv_len, kv_start, n_q_
     b = kv_len.numel()
     q2 = q.view(b, n_q_heads * 128)
     _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_decode_noalloc: q layout")
-    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+    _need(k_cache.dtype == q2.dtype and v_cache.dtype == q2.dtype and k_cache.is_contiguous() and v_cache.is_contiguous() and
           tuple(k_cache.shape[-2:]) == (n_kv_heads, 128) and v_cache.shape == k_cache.shape, "paged_decode_noalloc: cache layout")
     _need(kv_indices.dtype == torch.int32 and kv_indices.is_contiguous(), "paged_decode_noalloc: kv_indices must be int32")
     _need(kv_len.dtype == torch.int32 and kv_len.is_contiguous() and kv_start.dtype == torch.int64 and kv_start.is_contiguous()
@@ -322,16 +329,16 @@ def paged_prefill(q, k_cache, v_cache, qo_indptr, kv_indptr, kv_indices, plan_ws
     t = q.shape[0]
     b = qo_indptr.numel() - 1
     q2 = q.view(t, n_q_heads * 128)
-    _need(q2.dtype == BF16 and q2.stride(1) == 1, "paged_prefill: q layout")
-    _need(k_cache.dtype == BF16 and k_cache.is_contiguous() and v_cache.is_contiguous() and
+    _need(q2.dtype in H16 and q2.stride(1) == 1, "paged_prefill: q layout")
+    _need(k_cache.dtype == q2.dtype and v_cache.dtype == q2.dtype and k_cache.is_contiguous() and v_cache.is_contiguous() and
           tuple(k_cache.shape[-2:]) == (n_kv_heads, 128) and v_cache.shape == k_cache.shape, "paged_prefill: cache layout")
     for name, x in (("qo_indptr", qo_indptr), ("kv_indptr", kv_indptr), ("kv_indices", kv_indices)):
         _need(x.dtype == torch.int32 and x.is_contiguous(), f"paged_prefill: {name} must be contiguous int32")
     _need(kv_indptr.numel() == b + 1, "paged_prefill: indptr lengths differ")
     if out is None:
-        out = torch.empty((t, n_q_heads * 128), dtype=BF16, device=q.device)
+        out = torch.empty((t, n_q_heads * 128), dtype=q2.dtype, device=q.device)
     lib = _lib.load()
-    _lib.check(lib.nvx_paged_prefill(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(qo_indptr),
+    _lib.check(_fn(lib, "nvx_paged_prefill", q2.dtype)(_ptr(q2), q2.stride(0), _ptr(k_cache), _ptr(v_cache), k_cache.shape[0], _ptr(qo_indptr),
                                      _ptr(kv_indptr), _ptr(kv_indices), _ptr(plan_ws), _ptr(out), t, b, n_q_heads, n_kv_heads,
                                      float(sm_scale), _stream()), "nvx_paged_prefill")
     return out

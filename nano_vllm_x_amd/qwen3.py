@@ -94,7 +94,7 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Ten
     follows sums; "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
     rows, k = x.shape
     n = weight.shape[0]
-    use = (x.is_cuda and x.dtype == torch.bfloat16 and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
+    use = (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
            and n * k * 2 <= DECODE_LINEAR_MAX_WEIGHT_BYTES)
     if kind in ("o", "down"):
         splits = ops.linear_decode_splits(n, k) if use and not tpd.collectives_active() and n % 16 == 0 else 0

@@ -65,10 +65,10 @@ def test_tiny_qwen3_logits_match_reference_eager_and_graph():
         check_logits("g7_reference_vs_hip_unfused", got_unfused[step], g[f"logits{step}"], f"step {step}")
 
 
-def test_float16_checkpoint_is_served_in_bfloat16():
-    """A checkpoint whose config says float16 (the reference's default dtype, model_runner.py:14-23) loads and runs:
-    its tensors are converted to bfloat16, the dtype the kernels compute in.  The logits are those of the same values
-    handed over as a bfloat16 checkpoint, bit for bit, and stay within the measured bound of the reference's."""
+def test_float32_checkpoint_is_served_in_bfloat16():
+    """The kernels are built for the two 16-bit formats (a float16 checkpoint runs in float16: test_gpu_float16.py).  A
+    checkpoint whose config says float32 loads and runs with its tensors converted to bfloat16 (same exponent range):
+    the logits are those of the same values handed over as a bfloat16 checkpoint, bit for bit."""
     import dataclasses
 
     from nano_vllm_x_amd.core.model_runner import ModelRunner
@@ -76,7 +76,7 @@ def test_float16_checkpoint_is_served_in_bfloat16():
     from tiny_model import tiny_state_dict
 
     meta = golden_json("g7_tiny_qwen3.json")
-    as_f16 = {k: v.to(torch.float16) for k, v in tiny_state_dict(meta["config"]).items()}   # the float16 checkpoint
+    as_f32 = {k: v.float() for k, v in tiny_state_dict(meta["config"]).items()}
     base = Qwen3Config.from_dict(meta["config"])
 
     def run(cfg, sd):
@@ -85,12 +85,12 @@ def test_float16_checkpoint_is_served_in_bfloat16():
         r.initialize_kv_cache(64)
         return r, _run_fixture(r, meta)
 
-    r16, got = run(dataclasses.replace(base, torch_dtype="float16"), as_f16)
-    assert r16.checkpoint_dtype == torch.float16 and r16.dtype == torch.bfloat16
-    _, want = run(base, {k: v.to(torch.bfloat16) for k, v in as_f16.items()})   # the same values, converted beforehand
+    r32, got = run(dataclasses.replace(base, torch_dtype="float32"), as_f32)
+    assert r32.checkpoint_dtype == torch.float32 and r32.dtype == torch.bfloat16
+    _, want = run(base, {k: v.to(torch.bfloat16) for k, v in as_f32.items()})   # the same values, converted beforehand
     for step in range(3):
         assert np.array_equal(got[step], want[step]), step
-        check_logits("g7_reference_vs_hip_eager", got[step], golden_npz("g7_tiny_qwen3.npz")[f"logits{step}"], f"float16 checkpoint, step {step}")
+        check_logits("g7_reference_vs_hip_eager", got[step], golden_npz("g7_tiny_qwen3.npz")[f"logits{step}"], f"float32 checkpoint, step {step}")
 
 
 def test_engine_greedy_streams_identical_eager_vs_graph():
