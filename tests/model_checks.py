@@ -38,6 +38,7 @@ MEASURED: dict = {
     "g7_reference_vs_hip_unfused": 0.00840336,
     "g7_unfused_vs_fused": 0,
     "pp2_vs_one_rank": 0,
+    "tiny_f16_hip_vs_f16_cpu": 0.00158144,
     "tiny_f16_hip_vs_fp32_cpu": 0.00143307,
     "tp2_vs_one_rank": 0.011239,
 }

@@ -267,6 +267,12 @@ def test_tiny_model_in_float16_against_the_fp32_oracle():
     n = len(meta["prompts"])
     want = cpu_engine_greedy_oracle(meta["config"], {k: v.float() for k, v in sd16.items()}, [list(p) for p in meta["prompts"]], [3] * n, 64, 4, 64,
                                     forced={i: [meta["feed"][0][i], meta["feed"][1][i], 0] for i in range(n)})
+    # ... and with the oracle itself computing in float16 (the reference's eager arithmetic in its default dtype; that run
+    # is 1.7e-3 of the largest logit away from the fp32 one)
+    want16 = cpu_engine_greedy_oracle(meta["config"], sd16, [list(p) for p in meta["prompts"]], [3] * n, 64, 4, 64, dtype=F16,
+                                      forced={i: [meta["feed"][0][i], meta["feed"][1][i], 0] for i in range(n)})
     for step in range(3):
-        ref = np.stack([want["logits"][i][step].numpy() for i in range(n)]).astype(np.float32)
+        ref = np.stack([want["logits"][i][step].float().numpy() for i in range(n)])
         check_logits("tiny_f16_hip_vs_fp32_cpu", first[step], ref, f"step {step}")
+        ref16 = np.stack([want16["logits"][i][step].float().numpy() for i in range(n)])
+        check_logits("tiny_f16_hip_vs_f16_cpu", first[step], ref16, f"step {step}")
