@@ -210,11 +210,38 @@ def prefill_attention_roofline(runner, prompts, reps: int = 8):
     e1.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flop = 4 * hq * 128 * sum(l * (l + 1) // 2 for l in lens)
+    # Bytes a launch must move at least once: q and out rows, K and V rows, slot ids.  On this batch (short prompts) they
+    # put the kernel UNDER the ridge of the roofline (2.5 PFLOP/s over 8 TB/s = 312 flop/B): what the chip could attain
+    # is the HBM time of those bytes, not the matrix peak; both fractions are reported, `frac` stays the matrix one.
+    compulsory = total * (2 * hq * 256 + 2 * hkv * 256) + 4 * total
+    attainable = min(MFMA_BF16_PEAK_TFLOPS, flop / (compulsory / (HBM_PEAK_GBS * 1e9)) / 1e12)
     return {"bound": "mfma", "achieved": round(flop / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _pmc_prefill_traffic(),
             "kernel": "paged_prefill_kernel<2,4> (nvx_paged_prefill)", "launches": reps,
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops": flop,
+            "compulsory_bytes": compulsory, "flop_per_byte": round(flop / compulsory, 1),
+            "hbm_floor_us": round(compulsory / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+            "attainable_tflops (min of the matrix peak and flop_per_byte x 8 TB/s)": round(attainable, 1),
+            "frac_of_attainable": round(flop / sec / 1e12 / attainable, 4),
+            "hbm_frac (compulsory bytes / time / 8 TB/s)": round(compulsory / sec / (HBM_PEAK_GBS * 1e9), 4),
             "batch": f"{len(lens)} prompts, {total} tokens, causal, nothing cached"}
+
+
+def _pmc_prefill_traffic():
+    """HBM bytes per launch of the prefill kernel on this batch from the committed counter summary, if it was taken from
+    the kernel source this run uses (else None)."""
+    import hashlib
+
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_prefill.json")) as f:
+            d = json.load(f)
+        stamp = d["kernel_source"]
+        with open(os.path.join(ROOT, stamp["file"]), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest() != stamp["sha256"]:
+                return None
+        return int(d["derived"]["hbm_bytes (2 x FETCH_SIZE + WRITE_SIZE)"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def _pmc_traffic(kernel: str):

@@ -27,7 +27,9 @@ for i in range(4):
     ops.paged_prefill(q, kc[i % 2], vc[i % 2], indptr, indptr, idx, plan, HQ, HKV, 128 ** -0.5, out=out)
 torch.cuda.synchronize()
 flop = 4 * HQ * 128 * sum(l * (l + 1) // 2 for l in lens)
-info = {"launches": 4, "algorithmic_flop_per_launch": flop, "tokens": t_tok}
+# bytes every launch must move at least once: q and out rows (HQ x 256 B per token each), K and V rows (HKV x 256 B per token each)
+compulsory = t_tok * (2 * HQ * 256 + 2 * HKV * 256) + 4 * t_tok
+info = {"launches": 4, "algorithmic_flop_per_launch": flop, "tokens": t_tok, "compulsory_bytes_per_launch": compulsory}
 print(json.dumps(info))
 if len(sys.argv) > 1:
     with open(sys.argv[1], "w") as f:

@@ -2,7 +2,7 @@
 """Summarise the two rocprofv3 --pmc passes of tools/pmc_all.sh over tools/pmc_prefill.py (SQ counters of the prefill
 attention kernel on the bench workload's prompts).
 
-usage: pmc_prefill_summarise.py pf_info.json pass1_dir pass2_dir > profiles/rN_pmc_prefill.json
+usage: pmc_prefill_summarise.py pf_info.json pass1_dir pass2_dir [fetch_dir write_dir] > profiles/rN_pmc_prefill.json
 
 Counter units as rocprofv3 reports them on gfx950: SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over
 waves; SQ_BUSY_CYCLES per shader engine; SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs.
@@ -45,6 +45,15 @@ def main():
         "mfma_flop (SQ_INSTS_MFMA x 32768)": c["SQ_INSTS_MFMA"] * 32768,
         "algorithmic_flop": info["algorithmic_flop_per_launch"],
     }
+    if len(sys.argv) > 5:   # HBM traffic: FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950 (see pmc_summarise.py)
+        c.update(per_launch(sys.argv[4]))
+        c.update(per_launch(sys.argv[5]))
+        hbm = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+        d["hbm_bytes (2 x FETCH_SIZE + WRITE_SIZE)"] = hbm
+        d["compulsory_bytes (q, out, K and V rows once each)"] = info.get("compulsory_bytes_per_launch")
+        if info.get("compulsory_bytes_per_launch"):
+            d["hbm_bytes_over_compulsory"] = hbm / info["compulsory_bytes_per_launch"]
+            d["flop_per_compulsory_byte (ridge of 2.5 PFLOP/s over 8 TB/s: 312)"] = info["algorithmic_flop_per_launch"] / info["compulsory_bytes_per_launch"]
     out = {"source": "rocprofv3 --pmc (two passes, tools/pmc_all.sh) -- python3 tools/pmc_prefill.py",
            "kernel": "paged_prefill_kernel<2,4> (4 waves, 64 queries, two workgroups per CU, LDS-DMA gather)",
            "kernel_source": source_stamp("nano_vllm_x_amd/csrc/prefill_attn.hip"),
