@@ -144,12 +144,13 @@ __device__ __forceinline__ void pf_gather(unsigned ids, int krow0, unsigned n_sl
 
 #if defined(PF_STAMPS) && !defined(NVX_F16)
 // Build-time instrumentation (tools/build_variant.sh ... "-DPF_STAMPS"): shader-clock stamps of waves 0 and 3 of the
-// workgroups of query blocks 120 and 121 (kv head 0) at eight points of tiles 16..47, read back with nvx_debug_pf_stamps.
+// workgroups of blocks 8 and 9 (kv head 0; blocks of a sequence are taken last first, so these are query blocks 119 and
+// 118 of a 8 192-token sequence) at eight points of tiles 16..47, read back with nvx_debug_pf_stamps.
 // Never in the shipped library.
 __device__ unsigned long long pf_stamps[2 * 2 * 32 * 8];
 extern "C" int nvx_debug_pf_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pf_stamps), sizeof(pf_stamps)); }
 #define PF_STAMP(k) do { if (stamp_on && tile >= 16 && tile < 48 && lane == 0) \
-    pf_stamps[(((gblk - 120) * 2 + (wave ? 1 : 0)) * 32 + (tile - 16)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    pf_stamps[(((stamp_blk - 8) * 2 + (wave ? 1 : 0)) * 32 + (tile - 16)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PF_STAMP(k) do { } while (0)
 #endif
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
 #pragma unroll
     for (int w = 0; w < NWAVES; ++w) b += owner_count[w];
     b = __builtin_amdgcn_readfirstlane(b < 0 ? 0 : b);
-    const int qb = gblk - tab[1 + b];
+    // blocks of a sequence are taken last first: the last query block sees the most keys, and the launch should end
+    // on short blocks, not on the longest ones
+    const int qb = tab[2 + b] - 1 - gblk;
     const int q0 = qo_indptr[b], lq = qo_indptr[b + 1] - q0;
     const int kv0 = kv_indptr[b], lkv = kv_indptr[b + 1] - kv0;
     const int offset = lkv - lq;              // query i sees keys 0 .. i + offset
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     { const unsigned t0 = ids0; ids0 = ids1; ids1 = t0; }
     // at the top of tile t: ids0 holds the ids of tile t + 1, ids1 is free (its ids were used a tile ago)
 #ifdef PF_STAMPS
-    const bool stamp_on = (gblk == 120 || gblk == 121) && head == 0 && (wave == 0 || wave == 3);
+    const int stamp_blk = gblk;
+    const bool stamp_on = (gblk == 8 || gblk == 9) && head == 0 && (wave == 0 || wave == 3);
 #endif
     for (int tile = 0; tile < n_tiles; ++tile) {
         PF_STAMP(0);

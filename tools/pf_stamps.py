@@ -3,7 +3,7 @@
 (tools/build_variant.sh stamps prefill_attn "-DPF_STAMPS", copied over nano_vllm_x_amd/libnvx_hip.so on the box).
 
 Uniform long sequences (steady state of the loop); prints, for waves 0 and 3 of two workgroups, the mean
-shader-clock ticks spent between consecutive stamps of tiles 16..47 (query blocks 120 and 121 of the first sequence, kv head 0):
+shader-clock ticks spent between consecutive stamps of tiles 16..47 (blocks 8 and 9 of the launch = query blocks 119 and 118 of the first 8 192-token sequence, kv head 0):
   0 loop top | 1 next tile's copies issued | 2 QK^T MFMAs issued | 3 max, rescale done | 4 first probabilities
   | 5 PV done (issued) | 6 copies of the next tile landed | 7 barrier passed
 """
