@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/../nano_vllm_x_amd/csrc"
 name=$1; src=$2; defs=$3
 mkdir -p build/var_$name
+[ "$src" = prefill_attn ] && defs="$defs -fno-slp-vectorize"   # as the Makefile builds it
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $defs -c $src.hip -o build/var_$name/$src.o
 objs=""
 for o in build/*.o; do
