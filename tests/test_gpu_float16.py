@@ -199,6 +199,33 @@ def test_decode_from_raw_qkv_f16_matches_the_two_kernel_path(ops, hq, hkv):
     attn_close(got.view(b, hq, 128), want.view(b, hq, 128).float(), float(vc.float().abs().max()) if _uses_matrix_cores(hq, hkv) else 0.0)
 
 
+@pytest.fixture
+def half_cases(monkeypatch):
+    """The attention cases of test_gpu_kernels.py, built in float16 (tolerances follow: see ULP() there)."""
+    import test_gpu_kernels as t
+
+    monkeypatch.setattr(t, "DTYPE", F16)
+    return t
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2)])   # the register kernel and the LDS-ring + MFMA kernel
+def test_decode_edge_cases_in_float16(ops, half_cases, hq, hkv):
+    """Split sequences (merge kernel), a 2-D table, zero-length and one-key rows, slot ids out of range, scores in the
+    hundreds: the cases of the bfloat16 suite, through nvx_paged_decode_f16."""
+    half_cases.test_decode_attention_split_sequences(ops, hq, hkv)
+    half_cases.test_decode_zero_length_row_gives_zeros(ops, hq, hkv)
+    half_cases.test_decode_ragged_batch_with_empty_and_single_rows(ops, hq, hkv)
+    half_cases.test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops, hq, hkv)
+
+
+def test_prefill_edge_cases_in_float16(ops, half_cases):
+    """Cached prefixes, 700 short and empty sequences (multi-pass owner lookup), rows of a thousand keys: through
+    nvx_paged_prefill_f16, against the oracle and against per-row decode."""
+    half_cases.test_prefill_attention_with_cached_prefix(ops)
+    half_cases.test_prefill_many_short_sequences(ops)
+    half_cases.test_prefill_matches_oracle_long_rows(ops)
+
+
 @pytest.mark.parametrize("m", [1, 29, 64, 200])
 def test_decode_projections_f16_vs_fp32_reference(ops, m):
     """nvx_linear_decode_f16 (modes 0, 1, 2) and nvx_rmsnorm_splitk_f16 against fp32 arithmetic on the same float16 values."""

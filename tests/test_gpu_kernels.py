@@ -30,10 +30,20 @@ def ops():
     return _ops
 
 
+# The 16-bit format the attention cases below are built in.  tests/test_gpu_float16.py re-runs the edge cases with
+# float16 (the *_f16 entry points); the rounding terms of the tolerances follow the format (ULP: one unit in the last
+# place relative to the value, 2^-8 for bfloat16's 8 significant bits, 2^-11 for float16's 11).
+DTYPE = torch.bfloat16
+
+
+def ULP() -> float:
+    return 2.0 ** -8 if DTYPE == torch.bfloat16 else 2.0 ** -11
+
+
 def attn_close(got: torch.Tensor, want_f32: torch.Tensor, p_bf16_vmax: float = 0.0):
     got = got.float().cpu()
     want = want_f32.float().cpu()
-    tol = 1e-3 * torch.clamp(want.abs(), min=1.0) + want.abs() * 2.0 ** -8 + p_bf16_vmax * 2.0 ** -9 + 1e-6
+    tol = 1e-3 * torch.clamp(want.abs(), min=1.0) + want.abs() * ULP() + p_bf16_vmax * ULP() / 2 + 1e-6
     bad = (got - want).abs() > tol
     assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} outside tolerance; max err {(got - want).abs().max():.3e}"
 
@@ -175,8 +185,8 @@ def test_fused_qknorm_rope_store_vs_unfused_oracle(ops):
 
 # -----------------------------------------------------------------------------------------------
 def _random_cache(gen, slots, hkv, d=128):
-    kc = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
-    vc = torch.randn(slots, hkv, d, generator=gen).to(torch.bfloat16)
+    kc = torch.randn(slots, hkv, d, generator=gen).to(DTYPE)
+    vc = torch.randn(slots, hkv, d, generator=gen).to(DTYPE)
     return kc, vc
 
 
@@ -189,7 +199,7 @@ def _decode_case(ops, seed, lens, hq, hkv, slots=None, strided_table=False):
     slots = slots or max(64, 2 * total)
     kc, vc = _random_cache(gen, slots, hkv)
     perm = torch.randperm(slots, generator=gen)[:total].to(torch.int32)
-    q = torch.randn(b, hq, 128, generator=gen).to(torch.bfloat16)
+    q = torch.randn(b, hq, 128, generator=gen).to(DTYPE)
     indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
     ref = paged_attention_oracle(q.float(), kc, vc, np.arange(b + 1), indptr, perm.numpy(), 128 ** -0.5)
     ws = ops.DecodeWorkspace(b, hq, hkv, DEV)
@@ -240,7 +250,7 @@ def test_decode_attention_bench_like_batch(ops, hq, hkv):
 def test_decode_zero_length_row_gives_zeros(ops, hq, hkv):
     gen = torch.Generator().manual_seed(2)
     kc, vc = _random_cache(gen, 64, hkv)
-    q = torch.randn(2, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    q = torch.randn(2, hq * 128, generator=gen).to(DTYPE).to(DEV)
     ws = ops.DecodeWorkspace(2, hq, hkv, DEV)
     kv_len = torch.tensor([0, 3], dtype=torch.int32, device=DEV)
     kv_start = torch.tensor([0, 2], dtype=torch.int64, device=DEV)
@@ -285,7 +295,7 @@ def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
     slots = max(64, 2 * total)
     kc, vc = _random_cache(gen, slots, hkv)
     perm = torch.randperm(slots, generator=gen)[:total].to(torch.int32)
-    q = torch.randn(t, hq, 128, generator=gen).to(torch.bfloat16)
+    q = torch.randn(t, hq, 128, generator=gen).to(DTYPE)
     qo = np.concatenate(([0], np.cumsum(q_lens))).astype(np.int32)
     kp = np.concatenate(([0], np.cumsum(kv_lens))).astype(np.int32)
     qo_d, kp_d = torch.from_numpy(qo).to(DEV), torch.from_numpy(kp).to(DEV)
@@ -309,9 +319,9 @@ def _prefill_case(ops, seed, q_lens, kv_lens, hq, hkv, check_oracle=True):
     ops.decode_plan(kv_len, torch.tensor(row_start, dtype=torch.int64, device=DEV), ws)
     out2 = ops.paged_decode(q.to(DEV).view(t, hq * 128), kcd, vcd, perm.to(DEV), t, ws, 128 ** -0.5)
     torch.cuda.synchronize()
-    # two bf16 outputs of the same fp32 quantity: 1e-3 + one rounding each + the bf16 probabilities of the MFMA path
+    # two 16-bit outputs of the same fp32 quantity: 1e-3 + one rounding each + the 16-bit probabilities of the MFMA path
     d = (out.float() - out2.float()).abs()
-    tol = 2e-3 * torch.clamp(out2.float().abs(), min=1.0) + out2.float().abs() * 2.0 ** -7 + float(vc.float().abs().max()) * 2.0 ** -9
+    tol = 2e-3 * torch.clamp(out2.float().abs(), min=1.0) + out2.float().abs() * 2 * ULP() + float(vc.float().abs().max()) * ULP() / 2
     assert not (d > tol).any(), f"prefill vs per-row decode: max diff {d.max():.3e}"
 
 
@@ -650,7 +660,7 @@ def test_decode_ragged_batch_with_empty_and_single_rows(ops, hq, hkv):
     gen = torch.Generator().manual_seed(3)
     kc, vc = _random_cache(gen, 64, hkv)
     ws = ops.DecodeWorkspace(3, hq, hkv, DEV)
-    q = torch.randn(3, hq * 128, generator=gen).to(torch.bfloat16).to(DEV)
+    q = torch.randn(3, hq * 128, generator=gen).to(DTYPE).to(DEV)
     ops.decode_plan(torch.tensor([0, 0, 0], dtype=torch.int32, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV), ws)
     out = ops.paged_decode(q, kc.to(DEV), vc.to(DEV), torch.zeros(4, dtype=torch.int32, device=DEV), 3, ws, 0.1)
     assert not out.any(), "sequences with no keys must produce zeros"
@@ -731,7 +741,7 @@ def test_decode_masks_invalid_slot_ids_and_survives_extreme_scores(ops, hq, hkv)
     slots = 256
     kc, vc = _random_cache(gen, slots, hkv)
     kc = kc * 40            # q.k * scale reaches the hundreds: exp2 of the raw score would overflow
-    q = (torch.randn(2, hq, 128, generator=gen) * 4).to(torch.bfloat16)
+    q = (torch.randn(2, hq, 128, generator=gen) * 4).to(DTYPE)
     valid = [torch.randperm(slots, generator=gen)[:70].to(torch.int32), torch.randperm(slots, generator=gen)[:9].to(torch.int32)]
     # the listed slots of sequence 0 are interleaved with ids outside [0, slots): those are masked keys
     listed0 = torch.stack([valid[0], torch.full((70,), -1, dtype=torch.int32)], 1).flatten()
