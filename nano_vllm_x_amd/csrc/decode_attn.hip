@@ -373,6 +373,8 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
         // merge the four quarter-waves (they hold different tokens, same dims)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            // (through LDS on purpose: with four workgroups per CU the latency is covered and the vector ALU is the
+            // scarce unit; the in-ALU exchange of the ring kernel below measured 0.5 us slower here)
             float mall = fmaxf(m[g], __shfl_xor(m[g], 16, 64));
             mall = fmaxf(mall, __shfl_xor(mall, 32, 64));
             const float mref = mall == -INFINITY ? 0.f : mall;
@@ -643,8 +645,8 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
                 sv[r] = (mine4 >> r) & 1u ? sacc[r] * scale_log2 : -INFINITY;
                 mx = fmaxf(mx, sv[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, xor16(mx));
+            mx = fmaxf(mx, xor32(mx));
             const float m_new = fmaxf(m_run, mx);
             const float mref = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
@@ -709,8 +711,8 @@ __global__ __launch_bounds__(256, DEC_M_WPS) void paged_decode_mfma_kernel(
         }
 
         // the four quarter-waves saw different tokens: their row sums add up (the maxima already agree)
-        l_run += __shfl_xor(l_run, 16, 64);
-        l_run += __shfl_xor(l_run, 32, 64);
+        l_run += xor16(l_run);
+        l_run += xor32(l_run);
         // hand the wave's state to the workgroup through the (dead) ring: [head][16-byte piece] -> m, l, acc[8];
         // this lane holds dims 16 blk + 4 q .. +3 of head l16: half of piece 2 blk + (q >> 1)
         if (l16 < G) {

@@ -122,6 +122,23 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// The value of lane ^ 32 (a one-dimensional workgroup whose size is a multiple of 64: lane = threadIdx.x & 63), moved
+// in the vector ALU: v_permlane32_swap_b32 exchanges the upper half of one register with the lower half of another;
+// __shfl_xor(v, 32) would be a ds_bpermute_b32 round trip through LDS.  Given v in both operands, the first result
+// holds the values of lanes 0-31 in both halves and the second those of lanes 32-63 -- or, if the compiler gives both
+// operands one register, both results hold the halves exchanged: the selection below is right either way.
+__device__ __forceinline__ float xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32u) ? r[0] : r[1]);
+}
+// The value of lane ^ 16, the same way (v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the
+// even rows of another).
+__device__ __forceinline__ float xor16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16u) ? r[0] : r[1]);
+}
 __device__ __forceinline__ float quarter_sum(float v) {
     v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
     v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2

@@ -334,12 +334,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
                     st[kb][r] = key <= vis ? st[kb][r] : -INFINITY;
                 }
         }
-        float mx = -INFINITY;
+        // (one chain of maxima per 32-key block: the chains are dependent instructions, and two run side by side)
+        float mxb[NKB];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+        for (int kb = 0; kb < NKB; ++kb) {
+            mxb[kb] = st[kb][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 1; r < 16; ++r) mxb[kb] = fmaxf(mxb[kb], st[kb][r]);
+        }
+        float mx = NKB == 2 ? fmaxf(mxb[0], mxb[NKB - 1]) : mxb[0];
+        mx = fmaxf(mx, xor32(mx));
         const float m_new = fmaxf(m_run, mx * scale_log2);     // scale_log2 > 0
         const float mref = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_kernel(
     // turns its 32 x 128 block around in LDS (the tile buffers are free: the loop ended with a barrier;
     // rows 272 B apart keep the 8-byte writes off each other's banks and the 16-byte reads aligned) and
     // stores whole 256-byte rows, four per instruction.
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + xor32(l_run);
     {
         constexpr int ROW = 272;
         const unsigned stage = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave * 32 * ROW);
