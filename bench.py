@@ -427,6 +427,9 @@ def main():
         "vs_baseline_note": "reference README: 9032.37 tok/s on 1x A100 40GB (other hardware)",
     }
 
+    if world > 1:
+        from nano_vllm_x_amd import distributed as tpd
+        result["config"]["all_reduce"] = tpd.PEER_STATE      # which path the decode-sized all-reduces took
     if rank == 0 and not args.no_roofline:
         batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
                                                              args.context_len, args.roofline_every)

@@ -39,8 +39,9 @@ typedef void* nvx_stream_t;
  * (nano_vllm_x_amd/_lib.py) reads this line and refuses a library built from another header.
  * Bump it whenever a signature below changes.
  *   2: nvx_decode_step_setup gained `prev_ids`.
- *   3: float16 entry points (`*_f16`) added. */
-#define NVX_ABI_VERSION 3
+ *   3: float16 entry points (`*_f16`) added.
+ *   4: direct-peer all-reduce (`nvx_peer_*`) added. */
+#define NVX_ABI_VERSION 4
 
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
@@ -262,6 +263,54 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
                           nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Tensor-parallel all-reduce of a decode step, over memory the peers have mapped, fused with the
+ * RMSNorm that follows it.  Replaces the NCCL all-reduce behind the row-parallel linears and the
+ * vocab-parallel embedding (nanovllmx/distributed/communication_op.py:41-52,153-156, called from
+ * layers/linear.py:277-278 and layers/vocab_parallel_embedding.py:105) together with the
+ * RMSNorm.forward that consumes its result (layers/layernorm.py:17-36, models/qwen3.py:179-186).
+ * A ring all-reduce of a decode-sized tensor (<= 2 MiB) is bound by 2(tp-1) link latencies; here
+ * every rank writes its rows into every peer's landing buffer at once (the xGMI mesh is fully
+ * connected) and then reads only its own memory.
+ *
+ * A group is one rank's end of the exchange among tp_size <= 8 ranks (one process per GPU):
+ *   nvx_peer_create   allocates this rank's landing buffer on the current device (uncached device
+ *                     memory, nvx_peer_exchange_bytes() bytes), a per-row exchange counter and a
+ *                     status word in pinned host memory.  These three calls are the only ones in
+ *                     the library that allocate; they run once, at start-up.  timeout_ms bounds
+ *                     every wait inside the kernels (<= 0: 10 s).
+ *   nvx_peer_export   writes the 64-byte inter-process handle of the landing buffer; the host sends
+ *                     it to every peer by whatever channel it has (torch.distributed's object
+ *                     all-gather in this package).
+ *   nvx_peer_import   maps peer_rank's landing buffer from its handle (hipIpcOpenMemHandle).  All
+ *                     tp_size - 1 peers must be imported before the first exchange.
+ *   nvx_peer_status   0, or 1 once any wait of any exchange ran out (a peer died or fell more than
+ *                     timeout_ms behind): results since then are not to be trusted.
+ *   nvx_peer_destroy  unmaps and frees; every rank must have finished its exchanges (the host
+ *                     synchronises the ranks first).
+ *
+ * nvx_peer_allreduce_norm: x (rows, hidden) 16-bit, rows x_row_stride elements apart, is this
+ * rank's partial result; s = the sum over ranks, added in fp32 in rank order (identical bits on
+ * every rank) and rounded to the 16-bit format, as the all-reduce of 16-bit tensors hands it over.
+ *   weight == NULL:               y = s                      (the all-reduce alone; y may alias x)
+ *   weight, residual == NULL:     y = RMSNorm(s) * weight
+ *   weight, residual:             acc = s + residual in fp32, residual_out = round(acc),
+ *                                 y = RMSNorm(acc) * weight  (as nvx_rmsnorm)
+ * rows <= max_rows and hidden as given to nvx_peer_create; every rank of the group must make the
+ * same sequence of calls with the same rows (they run the same scheduler).  No allocation, no
+ * host synchronisation, hipGraph-capturable: the exchange counter lives in device memory and is
+ * advanced by the kernel.  One exchange at a time per group (one stream). */
+int64_t nvx_peer_exchange_bytes(int tp_size, int64_t max_rows, int64_t hidden);
+int nvx_peer_create(int tp_size, int rank, int64_t max_rows, int64_t hidden, int64_t timeout_ms,
+                    void** comm_out);
+int nvx_peer_export(void* comm, unsigned char* handle_out_64_bytes);
+int nvx_peer_import(void* comm, int peer_rank, const unsigned char* handle_64_bytes);
+int nvx_peer_status(void* comm);
+int nvx_peer_destroy(void* comm);
+int nvx_peer_allreduce_norm(void* comm, const void* x, int64_t x_row_stride, const void* residual,
+                            const void* weight, void* y, void* residual_out, int64_t rows,
+                            int64_t hidden, float eps, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * IEEE half (float16) builds of the entry points whose arithmetic depends on the 16-bit format.  The reference
  * resolves the dtype from the checkpoint and defaults to float16 (nanovllmx/core/model_runner.py:14-23,38-39).
  * Same arguments and semantics as the entry point without the suffix, with "16-bit floating point" meaning
@@ -303,6 +352,9 @@ int nvx_paged_prefill_f16(const void* q, int64_t q_row_stride, const void* k_cac
                       const int32_t* kv_indices, const int32_t* plan_ws, void* out,
                       int64_t n_tokens, int64_t batch, int n_q_heads, int n_kv_heads,
                       float sm_scale, nvx_stream_t stream);
+int nvx_peer_allreduce_norm_f16(void* comm, const void* x, int64_t x_row_stride, const void* residual,
+                            const void* weight, void* y, void* residual_out, int64_t rows,
+                            int64_t hidden, float eps, nvx_stream_t stream);
 
 #ifdef __cplusplus
 }

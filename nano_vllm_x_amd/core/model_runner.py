@@ -96,6 +96,9 @@ class ModelRunner:
             else:
                 self.model.init_random(self.seed)
         self.sampler = Sampler(seed=self.seed)
+        # tensor-parallel ranks: all-reduces of decode-sized tensors go peer to peer (set up and proven here, before
+        # the decode graph is captured; every rank falls back to the library all-reduce together if it cannot be)
+        tpd.init_peer_allreduce(self.max_bs, cfg.hidden_size, self.dtype, self.device)
 
     def profile_kv_cache_size(self, gpu_memory_utilization: float = 0.9) -> int:
         per_token = self.num_layers * self.num_kv_heads * self.head_dim * 2 * self.dtype.itemsize
@@ -278,6 +281,7 @@ class ModelRunner:
             out = self._sample_hosts[ids][:n].tolist()
         else:
             out = ids.tolist()
+        tpd.check_peer_status()      # a direct-peer exchange that gave up waiting must not pass as a result
         key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
         # launch to completion; a step queued behind another is charged from the moment that one completed
         now = time.perf_counter()

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import datetime
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -26,6 +27,17 @@ _TP_SIZE = 1
 _PP_RANK = 0
 _PP_SIZE = 1
 _FORCED = False    # one rank, but issue every collective anyway (NVX_FORCE_COLLECTIVES=1)
+_PEER = None       # ops.PeerGroup of this stage's TP group: decode-sized all-reduces go peer to peer, not through RCCL
+PEER_STATE = "off"  # why the direct-peer all-reduce is (not) in use: reported by bench.py
+
+
+class Unreduced:
+    """The output of a row-parallel projection that has not been summed over the ranks yet: the RMSNorm that consumes
+    it does the sum itself (one kernel: exchange with the peers, add, normalise)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
 
 
 def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | None = None, port: int = 29500,
@@ -119,9 +131,103 @@ def _via_host(x: torch.Tensor) -> bool:
     return x.is_cuda and dist.get_backend() == "gloo"
 
 
+def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) -> bool:
+    """Set up the direct-peer all-reduce for this stage's TP group (every rank of the group calls this at the same
+    point): allocate the landing buffer, exchange the inter-process handles through the process group, map the
+    peers, then PROVE the exchange on known data before trusting it -- three all-reduces whose result every rank can
+    compute by itself.  All ranks must pass, otherwise all fall back to the library all-reduce together.
+    NVX_PEER_AR=0 keeps it off; NVX_PEER_TIMEOUT_MS bounds the waits inside the kernels (default 10 s)."""
+    global _PEER, PEER_STATE
+    from . import ops, torch_ops  # noqa: F401  (registers torch.ops.nvx.*)
+    want = os.environ.get("NVX_PEER_AR", "1" if _TP_SIZE > 1 else "0")
+    if want == "0" or not collectives_active() or _PEER is not None or torch.device(device).type != "cuda":
+        if _PEER is None:
+            PEER_STATE = "off (NVX_PEER_AR=0)" if want == "0" and _TP_SIZE > 1 else "off"
+        return _PEER is not None
+    tp, rank = max(_TP_SIZE, 1), _TP_RANK
+    group, err = None, None
+    try:
+        if tp > 8:
+            raise RuntimeError("more than 8 ranks")
+        group = ops.PeerGroup(tp, rank, min(max(max_rows, 1), 512), hidden, int(os.environ.get("NVX_PEER_TIMEOUT_MS", "0")))
+        handle = group.export_handle() if tp > 1 else b""
+    except RuntimeError as e:      # every rank still takes part in the exchange below, so nobody waits for a rank that failed
+        err, handle = str(e), None
+    handles = [handle]
+    if tp > 1:
+        handles = [None] * tp
+        dist.all_gather_object(handles, handle, group=_TP_GROUP)
+    if err is None and all(h is not None for h in handles):
+        try:
+            for p in range(tp):
+                if p != rank:
+                    group.import_handle(p, handles[p])
+            rows = min(group.max_rows, 8)
+            pattern = (torch.arange(rows * hidden, device=device) % 8).view(rows, hidden)
+            for _ in range(3):     # both parities and the reuse of the first
+                x = (pattern * (rank + 1)).to(dtype)
+                torch.ops.nvx.peer_allreduce(group.comm, x)
+                torch.cuda.synchronize(device)
+                if group.status() != 0 or not torch.equal(x, (pattern * (tp * (tp + 1) // 2)).to(dtype)):
+                    raise RuntimeError("self-test: the exchanged sum is wrong" if group.status() == 0 else "self-test: a wait ran out")
+        except RuntimeError as e:
+            err = str(e)
+    elif err is None:
+        err = "a peer could not create its end"
+    oks = [err is None]
+    if tp > 1:
+        oks = [None] * tp
+        dist.all_gather_object(oks, err is None, group=_TP_GROUP)
+    if all(oks):
+        _PEER, PEER_STATE = group, f"direct-peer ({tp} ranks, {group.exchange_bytes >> 20} MiB landing buffer per rank)"
+        return True
+    if group is not None:
+        group.close()
+    PEER_STATE = f"library all-reduce (direct-peer set-up failed: {err or 'on another rank'})"
+    if rank == 0:
+        print(f"[nano_vllm_x_amd] {PEER_STATE}", file=sys.stderr, flush=True)
+    return False
+
+
+def peer_allreduce_active() -> bool:
+    return _PEER is not None
+
+
+def check_peer_status():
+    """Raise if a wait inside a direct-peer exchange ever ran out: the sums since then are not to be trusted."""
+    if _PEER is not None and _PEER.status() != 0:
+        raise RuntimeError("direct-peer all-reduce: a rank waited longer than the time-out for a peer's rows "
+                           "(a peer died or stalled); results since then are invalid")
+
+
+def tp_reduce_later(x: torch.Tensor):
+    """All-reduce of a row-parallel projection's output -- left to the RMSNorm that follows (Unreduced) when the
+    direct-peer exchange can take the tensor, done now otherwise."""
+    if _PEER is not None and _PEER.fits(x):
+        return Unreduced(x)
+    return tp_all_reduce(x)
+
+
+def tp_finish_reduce(x):
+    """The tensor behind an Unreduced (summed now), or x itself."""
+    if isinstance(x, Unreduced):
+        t = x.t if x.t.is_contiguous() else x.t.contiguous()
+        torch.ops.nvx.peer_allreduce(_PEER.comm, t)
+        return t
+    return x
+
+
+def peer_allreduce_norm(x: Unreduced, weight: torch.Tensor, eps: float, residual=None):
+    """RMSNorm.forward on an Unreduced input: exchange, sum, (+ residual,) normalise in one launch."""
+    y, res = torch.ops.nvx.peer_allreduce_norm(_PEER.comm, x.t, residual, weight, float(eps))
+    return y if residual is None else (y, res)
+
+
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     if _TP_SIZE > 1 or _FORCED:
-        if _via_host(x):
+        if _PEER is not None and x.is_contiguous() and _PEER.fits(x):
+            torch.ops.nvx.peer_allreduce(_PEER.comm, x)
+        elif _via_host(x):
             h = x.float().cpu() if x.dtype == torch.bfloat16 else x.cpu()
             dist.all_reduce(h, group=_TP_GROUP)
             x.copy_(h)
@@ -235,7 +341,14 @@ def barrier():
 
 
 def shutdown():
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED, _PEER, PEER_STATE
+    if _PEER is not None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist.is_initialized() and _TP_SIZE * _PP_SIZE > 1:
+            dist.barrier()          # no rank unmaps a landing buffer a peer's kernel may still write to
+        _PEER.close()
+        _PEER, PEER_STATE = None, "off"
     if dist.is_initialized():
         dist.destroy_process_group()
     _TP_GROUP, _TP_RANK, _TP_SIZE, _PP_RANK, _PP_SIZE, _FORCED = None, 0, 1, 0, 1, False

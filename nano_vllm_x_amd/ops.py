@@ -429,3 +429,71 @@ def decode_step_setup(step, stride, padded_batch, table, pad_start, kv_start, kv
     _lib.check(lib.nvx_decode_step_setup(_ptr(step), stride, padded_batch, _ptr(table), table.shape[0], table.shape[1], pad_start,
                                          _ptr(kv_start), _ptr(kv_len), _ptr(out_slots), _ptr(positions), _ptr(input_ids),
                                          _ptr(prev_ids) if prev_ids is not None else None, _stream()), "nvx_decode_step_setup")
+
+
+# ---------------------------------------------------------------------------------------------
+class PeerGroup:
+    """One rank's end of the direct-peer all-reduce of a tensor-parallel group (include/nvx.h, nvx_peer_*): a landing
+    buffer in uncached device memory that every peer has mapped, into which the peers' kernels write their rows.
+    Created once at start-up; `export_handle` / `import_handle` carry the 64-byte inter-process handles, which the
+    caller exchanges by its own means.  `_registry` lets the custom ops address a group by an integer."""
+
+    _registry: dict = {}
+
+    def __init__(self, tp_size: int, rank: int, max_rows: int, hidden: int, timeout_ms: int = 0):
+        import ctypes
+        lib = _lib.load()
+        comm = ctypes.c_void_p()
+        _lib.check(lib.nvx_peer_create(tp_size, rank, max_rows, hidden, timeout_ms, ctypes.byref(comm)), "nvx_peer_create")
+        self.comm, self.tp_size, self.rank, self.max_rows, self.hidden = comm.value, tp_size, rank, max_rows, hidden
+        self.exchange_bytes = int(lib.nvx_peer_exchange_bytes(tp_size, max_rows, hidden))
+        PeerGroup._registry[self.comm] = self
+
+    def export_handle(self) -> bytes:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(_lib.load().nvx_peer_export(self.comm, buf), "nvx_peer_export")
+        return buf.raw
+
+    def import_handle(self, peer_rank: int, handle: bytes):
+        _need(len(handle) == 64, "PeerGroup.import_handle: a handle is 64 bytes")
+        _lib.check(_lib.load().nvx_peer_import(self.comm, peer_rank, handle), "nvx_peer_import")
+
+    def status(self) -> int:
+        """0, or 1 once a wait inside an exchange ran out (a peer died or fell behind by more than the time-out)."""
+        return int(_lib.load().nvx_peer_status(self.comm)) if self.comm else -1
+
+    def close(self):
+        if self.comm:
+            PeerGroup._registry.pop(self.comm, None)
+            _lib.check(_lib.load().nvx_peer_destroy(self.comm), "nvx_peer_destroy")
+            self.comm = None
+
+    def fits(self, x) -> bool:
+        return self.comm is not None and x.dim() == 2 and x.shape[0] <= self.max_rows and x.shape[1] == self.hidden and x.dtype in H16 \
+            and x.stride(1) == 1
+
+
+def peer_allreduce_norm(group: PeerGroup, x, weight=None, eps: float = 0.0, residual=None):
+    """Sum of the ranks' `x` (rows, hidden), rounded to the 16-bit format; then, with `weight`, RMSNorm of it (of it plus
+    `residual`).  Returns the sum written over `x` (weight None), y, or (y, new_residual).  Every rank of the group
+    must make the same calls in the same order."""
+    _dev(x, weight, residual)
+    _need(group.fits(x), f"peer_allreduce_norm: x {tuple(x.shape)} {x.dtype} does not fit the group ({group.max_rows} rows x {group.hidden})")
+    rows, hidden = x.shape
+    lib = _lib.load()
+    if weight is None:
+        _need(residual is None, "peer_allreduce_norm: a residual needs the norm")
+        _need(x.stride(0) == hidden, "peer_allreduce_norm: the in-place sum needs contiguous rows")
+        _lib.check(_fn(lib, "nvx_peer_allreduce_norm", x.dtype)(group.comm, _ptr(x), x.stride(0), None, None, _ptr(x), None, rows, hidden, 0.0,
+                                                                 _stream()), "nvx_peer_allreduce_norm")
+        return x
+    _need(weight.dtype == x.dtype and weight.is_contiguous() and weight.numel() == hidden, "peer_allreduce_norm: weight")
+    y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+    res_out = None
+    if residual is not None:
+        _need(residual.dtype == x.dtype and residual.is_contiguous() and residual.shape == (rows, hidden), "peer_allreduce_norm: residual")
+        res_out = torch.empty_like(residual)
+    _lib.check(_fn(lib, "nvx_peer_allreduce_norm", x.dtype)(group.comm, _ptr(x), x.stride(0), _ptr(residual), _ptr(weight), _ptr(y), _ptr(res_out),
+                                                             rows, hidden, float(eps), _stream()), "nvx_peer_allreduce_norm")
+    return y if residual is None else (y, res_out)

@@ -151,7 +151,7 @@ class Qwen3Attention(nn.Module):
                                           md.output_kv_indices, k_cache, v_cache, self.num_heads, self.num_kv_heads)
                 attn_out = self.attn(q, None, None)
             out = decode_linear(attn_out, self.o_proj.weight, "o")
-            return out if out.dtype == torch.float32 else tpd.tp_all_reduce(out)
+            return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
         qkv = self.qkv_proj(hidden_states)
         if fused:
             k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
@@ -166,7 +166,7 @@ class Qwen3Attention(nn.Module):
             q, k = ops.rope(positions, q, k, self.rope_table)
             attn_out = self.attn(q, k, v.contiguous())
         out = self.o_proj(attn_out)
-        return tpd.tp_all_reduce(out)
+        return tpd.tp_reduce_later(out)
 
 
 class Qwen3MLP(nn.Module):
@@ -180,8 +180,8 @@ class Qwen3MLP(nn.Module):
     def forward(self, x, decode: bool = False):
         if decode:
             out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up"), self.down_proj.weight, "down")
-            return out if out.dtype == torch.float32 else tpd.tp_all_reduce(out)
-        return tpd.tp_all_reduce(self.down_proj(self.act_fn(self.gate_up_proj(x))))
+            return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
+        return tpd.tp_reduce_later(self.down_proj(self.act_fn(self.gate_up_proj(x))))
 
 
 class Qwen3DecoderLayer(nn.Module):
@@ -285,6 +285,7 @@ class Qwen3Model(nn.Module):
         for layer in self.local_layers():
             hidden_states, residual = layer(positions, hidden_states, residual, fused)
         if not tpd.pp_is_last():
+            hidden_states = tpd.tp_finish_reduce(hidden_states)    # an all-reduce no norm of this stage will do
             if hidden_states.dtype == torch.float32:   # K-split partial products of a skinny projection: sum them
                 hidden_states = hidden_states.sum(0).to(residual.dtype)
             return hidden_states, residual

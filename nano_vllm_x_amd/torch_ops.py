@@ -42,6 +42,9 @@ _DEFS = {
     "linear_decode": "(Tensor x, Tensor w, int mode, int k_splits) -> Tensor",
     "rmsnorm_splitk": "(Tensor partials, Tensor weight, float eps) -> Tensor",
     "rmsnorm_splitk_residual": "(Tensor partials, Tensor residual, Tensor weight, float eps) -> (Tensor, Tensor)",
+    # direct-peer all-reduce of a tensor-parallel group (`group`: the integer ops.PeerGroup.comm), alone or with the norm
+    "peer_allreduce": "(int group, Tensor(a!) x) -> ()",
+    "peer_allreduce_norm": "(int group, Tensor x, Tensor? residual, Tensor weight, float eps) -> (Tensor, Tensor)",
     # device-resident block table
     "block_table_write_rows": "(Tensor kv_indices, Tensor kv_indptr, Tensor rows, Tensor(a!) table) -> ()",
     "decode_step_setup": "(Tensor step, int stride, int padded_batch, Tensor(a!) table, int pad_start, Tensor(b!) kv_start, "
@@ -123,6 +126,17 @@ def _rmsnorm_splitk(partials, weight, eps):
 
 def _rmsnorm_splitk_residual(partials, residual, weight, eps):
     return ops.rmsnorm_splitk(partials, weight, eps, residual=residual)
+
+
+def _peer_allreduce(group, x):
+    ops.peer_allreduce_norm(ops.PeerGroup._registry[group], x)
+
+
+def _peer_allreduce_norm(group, x, residual: Optional[torch.Tensor], weight, eps):
+    g = ops.PeerGroup._registry[group]
+    if residual is None:
+        return ops.peer_allreduce_norm(g, x, weight, eps), x.new_empty(0)
+    return ops.peer_allreduce_norm(g, x, weight, eps, residual=residual)
 
 
 def _block_table_write_rows(kv_indices, kv_indptr, rows, table):

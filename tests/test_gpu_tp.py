@@ -32,7 +32,8 @@ CFG = dict(vocab_size=1000, hidden_size=512, intermediate_size=1536, num_hidden_
 PROMPT_LENS = (5, 19, 33, 8)
 
 
-def _run_model(tp: int, rank: int, port: int, pp: int = 1):
+def _run_model(tp: int, rank: int, port: int, pp: int = 1, eager: bool = True, peer: str = "1"):
+    os.environ["NVX_PEER_AR"] = peer if tp > 1 else "0"
     from nano_vllm_x_amd import distributed as tpd
     from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, SamplingParams, Sequence
     from nano_vllm_x_amd.core.model_runner import ModelRunner
@@ -40,7 +41,7 @@ def _run_model(tp: int, rank: int, port: int, pp: int = 1):
 
     if tp * pp > 1:
         tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port, pp_size=pp)
-    r = ModelRunner(model="tp-test", max_bs=8, tp_size=tp, enforce_eager=True, context_len=128,
+    r = ModelRunner(model="tp-test", max_bs=8, tp_size=tp, enforce_eager=eager, context_len=128,
                     config=Qwen3Config.from_dict(CFG), seed=5, pp_size=pp)
     r.load_model()           # seeded random weights: every rank draws the full matrices and keeps its shard
     r.initialize_kv_cache(512)
@@ -63,25 +64,29 @@ def _run_model(tp: int, rank: int, port: int, pp: int = 1):
             s.token_ids.append(int(rng.integers(0, CFG["vocab_size"])))
             s.kv_indices.append(s.kv_indices[-1] + 1)
     heads = (r.num_heads, r.num_kv_heads, r.num_layers)
+    LAST_RUN.update(peer_state=tpd.PEER_STATE, stats=dict(r.stats))
     r.shutdown()
     return logits, sampled[2], heads
 
 
-def _worker(rank, port, q, tp, pp):
+LAST_RUN: dict = {}     # how the last _run_model of this process ran (all-reduce path, step counters)
+
+
+def _worker(rank, port, q, tp, pp, eager=True, peer="1"):
     try:
-        out = _run_model(tp, rank, port, pp)
-        q.put((rank, out, None))
+        out = _run_model(tp, rank, port, pp, eager, peer)
+        q.put((rank, out + (dict(LAST_RUN),), None))
     except Exception:   # noqa: BLE001
         q.put((rank, None, traceback.format_exc()))
 
 
-def _run_ranks(tp: int, pp: int) -> dict:
+def _run_ranks(tp: int, pp: int, eager: bool = True, peer: str = "1") -> dict:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, q, tp, pp)) for r in range(tp * pp)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, tp, pp, eager, peer)) for r in range(tp * pp)]
     for p in procs:
         p.start()
     results = {}
@@ -108,15 +113,47 @@ def test_two_pipeline_stages_on_one_gpu_match_one_rank():
     assert results[0][1] == results[1][1] == want_ids      # greedy ids, broadcast from the last stage
 
 
-def test_two_ranks_on_one_gpu_match_one_rank():
-    results = _run_ranks(2, 1)
+@pytest.mark.parametrize("peer", ["1", "0"])
+def test_two_ranks_on_one_gpu_match_one_rank(peer):
+    """peer "1": the all-reduces of the row-parallel projections and of the embedding go peer to peer (fused with
+    the norms); "0": through the process group (gloo, staged through the host)."""
+    results = _run_ranks(2, 1, peer=peer)
     want, want_ids, heads1 = _run_model(1, 0, 0)
     assert heads1 == (8, 2, 2) and results[0][2] == (4, 1, 2)
+    for r in range(2):
+        assert results[r][3]["peer_state"].startswith("direct-peer" if peer == "1" else "off"), results[r][3]
     for step in range(3):
         a0, a1, b = results[0][0][step], results[1][0][step], want[step]
         assert np.array_equal(a0, a1), "ranks disagree after the LM-head gather"
         check_logits("tp2_vs_one_rank", a0, b, f"step {step}")
     assert results[0][1] == results[1][1] == want_ids      # greedy ids, broadcast from rank 0
+
+
+def test_four_ranks_with_replicated_kv_heads_match_one_rank():
+    """Four ranks over two kv heads: each kv head lives on two ranks (linear.py:333-338); direct-peer all-reduce."""
+    results = _run_ranks(4, 1)
+    want, want_ids, _ = _run_model(1, 0, 0)
+    assert results[0][2] == (2, 1, 2) and results[3][3]["peer_state"].startswith("direct-peer")
+    for step in range(3):
+        for r in range(1, 4):
+            assert np.array_equal(results[0][0][step], results[r][0][step]), "ranks disagree after the LM-head gather"
+        check_logits("tp4_vs_one_rank", results[0][0][step], want[step], f"step {step}")
+    assert all(results[r][1] == want_ids for r in range(4))
+
+
+def test_tensor_parallel_decode_graph_with_direct_peer_allreduce():
+    """With the all-reduces peer to peer, a tensor-parallel rank's decode step holds no process-group call and is
+    captured as a hipGraph even where the process group cannot be (gloo ranks sharing one GPU): both decode steps
+    must replay from the graph and give the eager run's logits bit for bit, on every rank."""
+    graph = _run_ranks(2, 1, eager=False)
+    eager = _run_ranks(2, 1, eager=True)
+    for r in range(2):
+        st = graph[r][3]["stats"]
+        assert st["graph_steps"] == st["decode_steps"] >= 2 and st["eager_decode_steps"] == 0, st
+        assert eager[r][3]["stats"]["graph_steps"] == 0
+        for step in range(3):
+            assert np.array_equal(graph[r][0][step], eager[r][0][step]), f"rank {r} step {step}: graph replay differs from eager launches"
+    assert graph[0][1] == graph[1][1] == eager[0][1]
 
 
 # -- several batches in flight across the stages --------------------------------------------------
