@@ -134,7 +134,7 @@ def _via_host(x: torch.Tensor) -> bool:
 def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) -> bool:
     """Set up the direct-peer all-reduce for this stage's TP group (every rank of the group calls this at the same
     point): allocate the landing buffer, exchange the inter-process handles through the process group, map the
-    peers, then PROVE the exchange on known data before trusting it -- three all-reduces whose result every rank can
+    peers, then PROVE the exchange on known data before trusting it -- 32 all-reduces whose result every rank can
     compute by itself.  All ranks must pass, otherwise all fall back to the library all-reduce together.
     NVX_PEER_AR=0 keeps it off; NVX_PEER_TIMEOUT_MS bounds the waits inside the kernels (default 10 s)."""
     global _PEER, PEER_STATE
@@ -162,9 +162,12 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
             for p in range(tp):
                 if p != rank:
                     group.import_handle(p, handles[p])
-            rows = min(group.max_rows, 8)
-            pattern = (torch.arange(rows * hidden, device=device) % 8).view(rows, hidden)
-            for _ in range(3):     # both parities and the reuse of the first
+            # 32 exchanges of full height on data every rank can derive by itself (small integers: sums are exact in
+            # both 16-bit formats), so that both slot parities are reused many times; a few milliseconds in all
+            rows = group.max_rows
+            base = torch.arange(rows * hidden, device=device).view(rows, hidden)
+            for it in range(32):
+                pattern = (base + it) % 7
                 x = (pattern * (rank + 1)).to(dtype)
                 torch.ops.nvx.peer_allreduce(group.comm, x)
                 torch.cuda.synchronize(device)

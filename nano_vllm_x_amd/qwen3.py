@@ -91,13 +91,20 @@ DECODE_LINEAR_MAX_WEIGHT_BYTES = 16 << 20
 def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
     """Projection of a decode batch.  Returns bf16 (rows, n) -- or, for the row-parallel projections
     ("o", "down") on a single rank, fp32 partial products (splits, rows, n) that the RMSNorm which
-    follows sums; "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
+    follows sums (under tensor parallelism they stay 16-bit: the sum over ranks comes first);
+    "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
     rows, k = x.shape
     n = weight.shape[0]
     use = (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
            and n * k * 2 <= DECODE_LINEAR_MAX_WEIGHT_BYTES)
     if kind in ("o", "down"):
-        splits = ops.linear_decode_splits(n, k) if use and not tpd.collectives_active() and n % 16 == 0 else 0
+        if tpd.collectives_active():
+            # a tensor-parallel rank hands its partial result to the all-reduce in the 16-bit format (linear.py:277-278);
+            # its share of K is 1/tp of the full one, which the skinny kernel takes whole where it is 512, 768 or 1024
+            if use and k in (512, 768, 1024) and n % 16 == 0:
+                return ops.linear_decode(x, weight, mode=0)
+            return F.linear(x, weight)
+        splits = ops.linear_decode_splits(n, k) if use and n % 16 == 0 else 0
         if splits:
             return ops.linear_decode(x, weight, mode=2, k_splits=splits)
         return F.linear(x, weight)
