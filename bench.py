@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--max-prefill-tokens", type=int, default=0,
                     help="> 0: admit prompts in prefill steps of at most this many tokens (0 = one step for the burst, as the reference)")
     ap.add_argument("--run-ahead", type=int, default=1,
-                    help="1: queue decode step N+1 before step N's ids reach the host (same batches, same tokens; one rank only)")
+                    help="1: queue decode step N+1 before step N's ids reach the host (same batches, same tokens on every rank)")
     ap.add_argument("--cpu-requests", type=int, default=8)
     ap.add_argument("--cpu-new-tokens", type=int, default=48)
     ap.add_argument("--roofline-every", type=int, default=8)
@@ -375,7 +375,7 @@ def main():
         kv_size = 2_000_000
     llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
               context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size,
-              run_ahead=bool(args.run_ahead) and world == 1, max_prefill_tokens=args.max_prefill_tokens or None)
+              run_ahead=bool(args.run_ahead), max_prefill_tokens=args.max_prefill_tokens or None)
     init_s = time.perf_counter() - t_init
     eng = llm.engine
 

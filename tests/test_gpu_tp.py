@@ -156,6 +156,70 @@ def test_tensor_parallel_decode_graph_with_direct_peer_allreduce():
     assert graph[0][1] == graph[1][1] == eager[0][1]
 
 
+# -- run-ahead on tensor-parallel ranks -----------------------------------------------------------------
+def _run_tp_engine(rank, tp, port, q, run_ahead):
+    try:
+        os.environ["NVX_PEER_AR"] = "1"
+        from nano_vllm_x_amd import distributed as tpd
+        from nano_vllm_x_amd.core.common import SamplingParams
+        from nano_vllm_x_amd.core.engine import Engine
+        from nano_vllm_x_amd.qwen3 import PRESETS
+
+        PRESETS["tp-engine-test"] = dict(CFG)
+        tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port)
+        eng = Engine("tp-engine-test", 0.5, max_bs=8, tp_size=tp, enforce_eager=False, context_len=128, kv_cache_size=1024, seed=5,
+                     run_ahead=run_ahead)
+        rng = np.random.default_rng(4)
+        want = {}
+        for i in range(6):
+            n_new = int(rng.integers(6, 14))
+            want[f"q{i}"] = n_new
+            eng.add_sequence(f"q{i}", rng.integers(0, CFG["vocab_size"], size=int(rng.integers(4, 30))).tolist(),
+                             SamplingParams(temperature=0.8, ignore_eos=True, max_new_tokens=n_new))
+        got = {k: [] for k in want}
+        for _ in range(400):
+            if not (eng.has_unfinished_sequences() or eng.step_in_flight):
+                break
+            for o in eng.step_overlapped():
+                got[o.seq_id].append(o.new_token_id)
+        stats = dict(eng.model_runner.stats)
+        ahead = eng.ahead_steps
+        eng.shutdown()
+        q.put((rank, (got, want, stats, ahead), None))
+    except Exception:   # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_run_ahead_on_tensor_parallel_ranks_generates_the_same_streams():
+    """Two ranks, decode steps replayed from the graph with direct-peer all-reduces inside, step N+1 queued before
+    step N's ids have reached the host: the decision to queue ahead depends on the scheduler's state alone, which
+    is the same on every rank, so the ranks stay in lockstep and the sampled streams equal those without it."""
+    runs = {}
+    for ra in (False, True):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_run_tp_engine, args=(r, 2, port, q, ra)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in procs:
+            rank, out, err = q.get(timeout=240)
+            assert err is None, f"rank {rank} failed:\n{err}"
+            res[rank] = out
+        for p in procs:
+            p.join(timeout=60)
+        assert res[0][0] == res[1][0], "ranks generated different tokens"
+        for k, n in res[0][1].items():
+            assert len(res[0][0][k]) == n
+        runs[ra] = res[0]
+    assert runs[True][0] == runs[False][0], "run-ahead changed the sampled streams"
+    assert runs[True][3] > 0 and runs[False][3] == 0
+    assert runs[True][2]["graph_steps"] > 0 and runs[True][2]["eager_decode_steps"] == 0
+
+
 # -- several batches in flight across the stages --------------------------------------------------
 def _run_engine(pp: int, rank: int, port: int):
     from nano_vllm_x_amd import distributed as tpd
