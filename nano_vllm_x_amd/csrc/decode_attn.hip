@@ -51,7 +51,8 @@ extern "C" int64_t nvx_decode_partial_ws_floats(int64_t max_batch, int n_q_heads
 __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __restrict__ kv_len,
                                                            const int64_t* __restrict__ kv_start,
                                                            const int64_t* __restrict__ out_slots, int batch, int hkv,
-                                                           int32_t* __restrict__ ws, int max_items, int target_units) {
+                                                           int32_t* __restrict__ ws, int max_items, int target_units,
+                                                           int min_chunk, int balanced) {
     __shared__ long long red[16];
     __shared__ int scan[1024];
     __shared__ int carry;
@@ -68,15 +69,21 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
     // Chunks sized for about `target_units` work units of similar length.  (Leaving sequences whole
     // at large batch saves the merge but was measured slower: units of unequal length leave a tail.)
     long long c = (total * hkv + target_units - 1) / target_units;
-    c = ((c + DEC_MIN_CHUNK - 1) / DEC_MIN_CHUNK) * DEC_MIN_CHUNK;
-    if (c < DEC_MIN_CHUNK) c = DEC_MIN_CHUNK;
+    c = ((c + min_chunk - 1) / min_chunk) * min_chunk;
+    if (c < min_chunk) c = min_chunk;
     const int chunk = (int)(c > DEC_MAX_CHUNK ? DEC_MAX_CHUNK : c);   // small enough that len + chunk cannot overflow
     int32_t* recs = ws + 8;
     int32_t* seq_info = recs + (int64_t)DEC_REC_INTS * max_items;
     for (int base = 0; base < batch; base += 1024) {
         const int b = base + tid;
-        int nch = 0, len = 0;
-        if (b < batch) { len = kv_len[b]; len = len > 0 ? len : 0; nch = len > 0 ? (int)(((long long)len + chunk - 1) / chunk) : 1; }
+        int nch = 0, len = 0, per = chunk;
+        if (b < batch) {
+            len = kv_len[b]; len = len > 0 ? len : 0; nch = len > 0 ? (int)(((long long)len + chunk - 1) / chunk) : 1;
+            if (balanced && nch > 1) {   // chunks of one sequence of equal length (a multiple of 32 tokens) instead of a short last one
+                per = (int)((((long long)len + nch - 1) / nch + 31) / 32 * 32);
+                nch = (int)(((long long)len + per - 1) / per);
+            }
+        }
         scan[tid] = nch;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -94,9 +101,9 @@ __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t* __rest
             long long new_slot = out_slots ? out_slots[b] : -1;
             if (new_slot < 0 || new_slot > 0x7fffffffll || len == 0) new_slot = -1;
             for (int i = 0; i < nch && first + i < max_items; ++i) {
-                const long long left = (long long)len - (long long)i * chunk;
-                const int n = (int)(left > chunk ? chunk : left);
-                const int64_t abs = start + (int64_t)i * chunk;
+                const long long left = (long long)len - (long long)i * per;
+                const int n = (int)(left > per ? per : left);
+                const int64_t abs = start + (int64_t)i * per;
                 int32_t* r = recs + (int64_t)DEC_REC_INTS * (first + i);
                 r[0] = b; r[1] = n; r[2] = nch; r[3] = i;
                 r[4] = (int32_t)(abs & 0xffffffffll); r[5] = (int32_t)(abs >> 32); r[6] = 0; r[7] = i == nch - 1 ? (int32_t)new_slot : -1;
@@ -127,8 +134,11 @@ extern "C" int nvx_decode_plan(const int32_t* kv_len, const int64_t* kv_start, c
     static int env_target = -1;
     if (env_target < 0) { const char* e = getenv("NVX_DEC_TARGET"); env_target = e ? atoi(e) : 0; if (env_target < 64 || env_target > 2048) env_target = 0; }
     const int target = env_target ? env_target : (n_kv_heads <= 2 ? 512 : DEC_TARGET_UNITS);
+    static int env_min = -1, env_bal = -1;
+    if (env_min < 0) { const char* e = getenv("NVX_DEC_MIN_CHUNK"); env_min = e ? atoi(e) : 0; if (env_min < 32 || env_min > 4096 || env_min % 32) env_min = DEC_MIN_CHUNK; }
+    if (env_bal < 0) { const char* e = getenv("NVX_DEC_BALANCED"); env_bal = e ? (atoi(e) ? 1 : 0) : 0; }
     hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_len, kv_start, out_slots, (int)batch,
-                       n_kv_heads, plan_ws, (int)dec_max_items(batch, n_kv_heads), target);
+                       n_kv_heads, plan_ws, (int)dec_max_items(batch, n_kv_heads), target, env_min, env_bal);
     return nvx_check_launch("nvx_decode_plan");
 }
 
