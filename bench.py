@@ -392,7 +392,8 @@ def main():
     sync_all(world)
     wall = time.perf_counter() - t0
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=eng.model_runner.device)
+        # (a rehearsal with several ranks on one GPU talks through gloo: host tensors there)
+        w = torch.tensor([wall], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else eng.model_runner.device)
         torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
         wall = float(w.item())
     stats1 = eng.model_runner.stats
