@@ -175,6 +175,21 @@ def _timeout_worker(rank, tp, port, q):
         ops.peer_allreduce_norm(group, x)           # one good exchange
         torch.cuda.synchronize()
         ok_first = group.status() == 0 and bool((x == tp).all())
+        # shapes the group was not made for are refused on the host, before any launch (a kernel handed a wrong
+        # shape would write outside the landing buffers)
+        for bad in (torch.ones(9, HIDDEN, dtype=torch.bfloat16, device=dev), torch.ones(4, HIDDEN // 2, dtype=torch.bfloat16, device=dev),
+                    torch.ones(4, HIDDEN, dtype=torch.float32, device=dev)):
+            try:
+                ops.peer_allreduce_norm(group, bad)
+            except RuntimeError:
+                pass
+            else:
+                raise AssertionError(f"a tensor of shape {tuple(bad.shape)} {bad.dtype} was accepted")
+        import ctypes
+        from nano_vllm_x_amd import _lib
+        lib = _lib.load()
+        rc = lib.nvx_peer_allreduce_norm(group.comm, x.data_ptr(), HIDDEN, None, None, x.data_ptr(), None, 9, HIDDEN, ctypes.c_float(0.0), None)
+        assert rc == -4 and b"9 rows" in lib.nvx_last_error(), (rc, lib.nvx_last_error())      # NVX_ENOSPACE from the C ABI itself
         dist.barrier()
         took = 0.0
         if rank == 0:                               # rank 1 never makes the second call: rank 0's wait must run out
