@@ -113,6 +113,21 @@ def test_two_pipeline_stages_on_one_gpu_match_one_rank():
     assert results[0][1] == results[1][1] == want_ids      # greedy ids, broadcast from the last stage
 
 
+def test_two_stages_of_two_tensor_parallel_ranks_match_one_rank():
+    """world 4 = 2 pipeline stages x 2 tensor-parallel ranks (the layout of the 32B configuration, scaled down): each
+    stage's TP group has its own direct-peer exchange; a stage that is not the last finishes its last all-reduce
+    itself (no norm of its own follows) before the pair goes to the next stage."""
+    results = _run_ranks(2, 2)
+    want, want_ids, _ = _run_model(1, 0, 0)
+    for r in range(4):
+        assert results[r][2] == (4, 1, 1) and results[r][3]["peer_state"].startswith("direct-peer"), results[r][2:]
+    for step in range(3):
+        assert results[0][0][step] is None and results[1][0][step] is None          # first stage: no logits
+        assert np.array_equal(results[2][0][step], results[3][0][step]), "the last stage's ranks disagree"
+        check_logits("tp2_pp2_vs_one_rank", results[2][0][step], want[step], f"step {step}")
+    assert all(results[r][1] == want_ids for r in range(4))
+
+
 @pytest.mark.parametrize("peer", ["1", "0"])
 def test_two_ranks_on_one_gpu_match_one_rank(peer):
     """peer "1": the all-reduces of the row-parallel projections and of the embedding go peer to peer (fused with
