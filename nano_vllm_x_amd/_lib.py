@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvx_hip.so")
+# NVX_LIB_PATH: another build of the same library (A/B timing of two versions of a kernel in one job)
+LIB_PATH = os.environ.get("NVX_LIB_PATH") or os.path.join(_HERE, "libnvx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nvx.h")
 
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ plan, float* __restrict__ partial, uint16_t* __restrict__ out, int hkv,
-    float scale_log2, DecQkv fx, int xmap, int max_items) {
+    float scale_log2, DecQkv fx) {
     constexpr int TILE = 4 * TPQ;
     constexpr int STEP = 4 * TILE;   // four waves interleave their tiles
     __shared__ float lds[4][G][16][10];  // [wave][head in group][piece] -> m, l, acc[8]
@@ -272,31 +272,13 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
 
     // The record of this block's first unit is fetched before the header says whether the unit exists:
     // blockIdx.x / hkv < max_items always, so the address is valid either way.
-    // Order of the units.  Plain: unit = item * hkv + head, so the eight kv heads of a chunk run on eight XCDs
-    // (workgroup i starts on XCD i % 8).  Grouped (xmap, hkv == 8): XCD x takes chunk 8g + x with its eight heads one
-    // after the other, so the workgroups that read the eight 256-byte pieces of the same 2 KB rows start together on
-    // one XCD and share the chunk's record and slot ids in its L2.  The item count is padded to a multiple of eight;
-    // units past the last item do nothing.
-    const bool xm = xmap != 0 && hkv == 8;
-    auto item_of = [&](int u) { return xm ? ((u >> 6) << 3) + (u & 7) : u / hkv; };
-    auto head_of = [&](int u) { return xm ? (u >> 3) & 7 : u % hkv; };
-    auto rec_of = [&](int u) { const int it = item_of(u); return it < max_items ? it : max_items - 1; };
     int unit = blockIdx.x;
-    nvx_u32x4 r0 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(unit));
-    nvx_u32x4 r1 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(unit) + 4);
-    const int n_items = plan[0];
-    const int n_units = xm ? ((n_items + 7) & ~7) * 8 : n_items * hkv;
+    nvx_u32x4 r0 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * (unit / hkv));
+    nvx_u32x4 r1 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * (unit / hkv) + 4);
+    const int n_units = plan[0] * hkv;
 
     while (unit < n_units) {
-        const int item = item_of(unit), head = head_of(unit);
-        if (item >= n_items) {   // padding of the grouped order
-            unit += gridDim.x;
-            if (unit < n_units) {
-                r0 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(unit));
-                r1 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(unit) + 4);
-            }
-            continue;
-        }
+        const int item = unit / hkv, head = unit % hkv;
         const int b = (int)r0[0], n = (int)r0[1], nch = (int)r0[2];
         const int64_t abs = (int64_t)(((uint64_t)r1[1] << 32) | (uint64_t)r1[0]);
         const int32_t* idx_base = kv_indices + abs;
@@ -428,8 +410,8 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
         // the next unit's record travels while the waves meet
         const int next_unit = unit + gridDim.x;
         if (next_unit < n_units) {
-            r0 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(next_unit));
-            r1 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * rec_of(next_unit) + 4);
+            r0 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * (next_unit / hkv));
+            r1 = *reinterpret_cast<const nvx_u32x4*>(recs + (int64_t)DEC_REC_INTS * (next_unit / hkv) + 4);
         }
         __syncthreads();
         if (tid < 16 * G) {
@@ -849,17 +831,14 @@ static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, 
     const int64_t max_units = dec_max_items(batch, n_kv_heads) * n_kv_heads;
     const unsigned grid = (unsigned)(max_units < 2048 ? max_units : 2048);
     const DecQkv none = {};
-    static int xmap = -1;    // NVX_DEC_XCDMAP: 1 = the eight kv heads of a chunk run on one XCD (8 kv heads only), 0 = on eight
-    if (xmap < 0) { const char* e = getenv("NVX_DEC_XCDMAP"); xmap = e ? (atoi(e) ? 1 : 0) : 0; }
-    const int max_items_i = (int)dec_max_items(batch, n_kv_heads);
 #define NVX_DEC(GG, TT, TQ)                                                                                                      \
     do {                                                                                                                         \
         if (fx) hipLaunchKernelGGL((paged_decode_kernel<GG, TQ, true>), dim3(grid), dim3(256), 0, st, (const uint16_t*)q, q_row_stride, \
                                    (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, partial_ws, \
-                                   (uint16_t*)out, n_kv_heads, scale_log2, *fx, xmap, max_items_i);                              \
+                                   (uint16_t*)out, n_kv_heads, scale_log2, *fx);                                                 \
         else hipLaunchKernelGGL((paged_decode_kernel<GG, TT, false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)q, q_row_stride,  \
                                 (const uint16_t*)k_cache, (const uint16_t*)v_cache, n_slots, kv_indices, plan_ws, partial_ws,    \
-                                (uint16_t*)out, n_kv_heads, scale_log2, none, xmap, max_items_i);                                \
+                                (uint16_t*)out, n_kv_heads, scale_log2, none);                                                   \
     } while (0)
     // tokens per quarter-wave per tile: plain variant / variant fed with the raw projection (which keeps
     // more values live across the loop, so it takes a smaller tile to stay within the same registers)
