@@ -40,7 +40,7 @@ typedef void* nvx_stream_t;
  * Bump it whenever a signature below changes.
  *   2: nvx_decode_step_setup gained `prev_ids`.
  *   3: float16 entry points (`*_f16`) added.
- *   4: direct-peer all-reduce (`nvx_peer_*`) added. */
+ *   4: direct-peer all-reduce (`nvx_peer_*`) and sharded sampling (`nvx_sample_shard`, `nvx_sample_pick`) added. */
 #define NVX_ABI_VERSION 4
 
 /* Library identification and diagnostics. */
@@ -230,6 +230,22 @@ int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_
                       const float* temperatures, const int64_t* top_ks, const float* top_ps,
                       const float* min_ps, int64_t batch, int64_t vocab, float* probs_out,
                       nvx_stream_t stream);
+
+/* Sampling on tensor-parallel ranks without gathering the logits.  The reference's LM head gathers every rank's
+ * (batch, vocab / tp) logits into full rows before Sampler.forward (nanovllmx/layers/vocab_parallel_embedding.py:147-151,
+ * core/model_runner.py:262-272).  For rows without a filter (top_k = all, top_p = 1, min_p = 0) and greedy rows the
+ * draw decomposes: nvx_sample_shard runs the draw of nvx_sample over this rank's shard -- logits (batch, shard_vocab),
+ * whose token j is token vocab_offset + j of the whole row (vocab_offset a multiple of 4; tokens >= vocab are padding
+ * and never drawn) -- and leaves one 64-bit (score, token) key per row in winner_out; the ranks exchange those keys
+ * (8 bytes per row) and nvx_sample_pick takes the largest of the n_sets keys of each row (winners is (n_sets, batch)):
+ * the same token, bit for bit, that nvx_sample draws from the gathered row with the same (seed, offset).
+ * ws as for nvx_sample (required here). */
+int nvx_sample_shard(const void* logits, int logits_is_f32, int64_t logits_row_stride,
+                     const float* temperatures, int64_t batch, int64_t shard_vocab, int64_t vocab_offset,
+                     int64_t vocab, uint64_t seed, uint64_t offset, uint64_t* winner_out, void* ws,
+                     int64_t ws_bytes, nvx_stream_t stream);
+int nvx_sample_pick(const uint64_t* winners, int64_t n_sets, int64_t batch, int64_t* out_ids,
+                    nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Device-resident block table for graph-replayed decode steps.  Replaces the per-step rebuild

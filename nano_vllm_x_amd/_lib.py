@@ -57,6 +57,8 @@ SIGNATURES = {
     "nvx_sample_ws_bytes": (_c_i64, [_c_i64]),
     "nvx_sample": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_vp, _c_i64, _c_vp]),
     "nvx_sampler_probs": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
+    "nvx_sample_shard": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_vp, _c_i64, _c_vp]),
+    "nvx_sample_pick": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "nvx_block_table_write_rows": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp]),
     "nvx_decode_step_setup": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "nvx_peer_exchange_bytes": (_c_i64, [_c_i32, _c_i64, _c_i64]),

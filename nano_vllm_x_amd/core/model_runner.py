@@ -58,11 +58,13 @@ class ModelRunner:
         self._config_override = config
         self.graph: Optional[HIPGraph] = None
         self.block_table: Optional[BlockTable] = None
-        self._sp_key, self._sp_dev = None, None
+        self._sp_key, self._sp_dev, self._sp_unfiltered = None, None, False
         self._stage_output, self._defer_stage_send = None, False
         self._last_done = 0.0
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
         self.graph_capture_error: Optional[str] = None    # set when a tensor-parallel decode graph could not be captured
+        # NVX_TP_SAMPLE=gather: tensor-parallel ranks always gather the logits and sample whole rows, as the reference does
+        self.shard_sampling = os.environ.get("NVX_TP_SAMPLE", "shard") != "gather"
 
     # -- set-up -----------------------------------------------------------------------------------
     def load_model(self, state_dict_iter=None):
@@ -164,6 +166,9 @@ class ModelRunner:
             sp = s.sampling_params
             host[0, i], host[1, i], host[2, i] = sp.temperature, sp.min_p, sp.top_p
             host[3, i] = v if sp.top_k == -1 else min(sp.top_k, v)
+        # no row with a filter (greedy rows, temperature <= 0, ignore theirs): tensor-parallel ranks can then draw from
+        # their own shards of the vocabulary and exchange 8 bytes per row instead of the logits
+        self._sp_unfiltered = bool(np.all((host[0] <= 0) | ((host[3] >= v) & (host[2] >= 1.0) & (host[1] <= 0.0))))
         dev = torch.from_numpy(host).to(self.device, non_blocking=True)
         self._sp_key, self._sp_dev = key, (dev[0], dev[1], dev[2], dev[3].to(torch.int64))
         return self._sp_dev
@@ -182,10 +187,11 @@ class ModelRunner:
             and batch.num_seqs <= self.graph.max_bs and self.block_table.fits(batch.seqs)
 
     @torch.inference_mode()
-    def compute_logits(self, batch: ForwardBatch, ids_on_device=None) -> torch.Tensor:
+    def compute_logits(self, batch: ForwardBatch, ids_on_device=None, shard: bool = False):
         """Forward pass of one scheduled batch -> logits (num_seqs, vocab) of each sequence's last token
         (None on a pipeline stage other than the last: its output went to the next stage).
-        `ids_on_device`: the input ids are ids the step before sampled (see launch_step)."""
+        `ids_on_device`: the input ids are ids the step before sampled (see launch_step).
+        `shard`: return (this rank's columns of the logits, id of their first token) instead of gathering the ranks'."""
         decode = batch.forward_mode == ForwardMode.DECODE
         if self.graph_step_possible(batch):
             hidden = self._execute_model_graph(batch, ids_on_device)
@@ -200,7 +206,7 @@ class ModelRunner:
         if hidden is None:
             return None
         hidden = self.prepare_last_hidden_states(batch, hidden)
-        return self.model.compute_logits(hidden)
+        return self.model.compute_logits_shard(hidden) if shard else self.model.compute_logits(hidden)
 
     @torch.inference_mode()
     def execute_model(self, batch: ForwardBatch) -> list:
@@ -219,9 +225,17 @@ class ModelRunner:
         if batch.num_seqs == 0:
             return None
         t0 = time.perf_counter()
-        logits = self.compute_logits(batch, ids_on_device)
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
+        if self.tp_size > 1 and self.pp_size == 1 and self._sp_unfiltered and n <= self.max_bs and self.shard_sampling:
+            # every rank draws over its own shard of the vocabulary; the ranks exchange one 64-bit key per row and all
+            # pick the same token: no gather of the logits (vocab_parallel_embedding.py:147-151), no broadcast of the ids
+            local, first = self.compute_logits(batch, ids_on_device, shard=True)
+            keys = self.sampler.forward_shard(local, temperatures, first, self.hf_config.vocab_size)
+            ids = ops.sample_pick(tpd.tp_all_gather_rows(keys), out=self._sample_out[:n])
+            self.stats["sharded_sampling_steps"] = self.stats.get("sharded_sampling_steps", 0) + 1
+            return (batch, self._ids_to_host(ids, n), t0)
+        logits = self.compute_logits(batch, ids_on_device)
         if logits is None:      # not the last pipeline stage: the ids arrive with the broadcast
             ids = self._sample_out[:n] if n <= self.max_bs else torch.empty(n, dtype=torch.int64, device=self.device)
         else:

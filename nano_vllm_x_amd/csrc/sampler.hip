@@ -116,15 +116,18 @@ template <bool F32>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(
     const void* __restrict__ logits, int64_t row_stride, const float* __restrict__ temps, const int64_t* __restrict__ top_ks,
     const float* __restrict__ top_ps, const float* __restrict__ min_ps, int vocab, uint64_t seed, uint64_t offset,
-    int64_t* __restrict__ out_ids, unsigned long long* __restrict__ winners, int n_split) {
+    int64_t* __restrict__ out_ids, unsigned long long* __restrict__ winners, int n_split, int tok0, int tok_end) {
+    // tok0 / tok_end: the row is the shard [tok0, tok0 + vocab) of a longer row whose tokens >= tok_end do not exist
+    // (padding of a vocabulary split over tensor-parallel ranks); noise and winner carry the token's id in the whole
+    // row, so the best of the shards' winners is the token a pass over the whole row draws.  0 / vocab otherwise.
+    // top_ks == nullptr (shards): no row has a filter.
     __shared__ BlockScratch sc;
     const int row = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
     const void* lrow = F32 ? (const void*)((const float*)logits + row * row_stride)
                            : (const void*)((const uint16_t*)logits + row * row_stride);
     const float T = temps[row];
     const bool greedy = !(T > 0.0f);
-    const int64_t k64 = top_ks[row];
-    const bool filtered = !greedy && ((k64 < vocab) || top_ps[row] < 1.0f || min_ps[row] > 0.0f);
+    const bool filtered = top_ks && !greedy && ((top_ks[row] < vocab) || top_ps[row] < 1.0f || min_ps[row] > 0.0f);
     if (filtered) {   // drawn by sample_filtered_kernel, which runs after this one and fills slice 0
         if (tid == 0 && winners) winners[(int64_t)row * n_split + slice] = 0ull;
         return;
@@ -132,19 +135,19 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
     // single pass: Gumbel-max over this workgroup's slice.  Four tokens share one Philox block.
     const int per = ((vocab + n_split - 1) / n_split + 3) & ~3;
-    const int lo = slice * per, hi = min(vocab, lo + per);
+    const int lo = slice * per, hi = min(min(vocab, lo + per), tok_end - tok0);
     const float inv_t = greedy ? 1.0f : 1.0f / T;
     float best = -INFINITY; int besti = 0x7fffffff;
     for (int base = lo + tid * 4; base < hi; base += SMP_THREADS * 4) {
         uint4 r = make_uint4(0, 0, 0, 0);
-        if (!greedy) r = philox4x32_10(make_uint4((uint32_t)(base >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)), key);
+        if (!greedy) r = philox4x32_10(make_uint4((uint32_t)((tok0 + base) >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)), key);
         const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = base + j;
             if (i < hi) {
                 const float v = load_logit<F32>(lrow, i) * inv_t + (greedy ? 0.0f : gumbel_from_bits(rr[j]));
-                if (v > best) { best = v; besti = i; }
+                if (v > best) { best = v; besti = tok0 + i; }
             }
         }
     }
@@ -836,14 +839,17 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_resident_kernel(
 }
 #undef SMP_ROWS
 
-// Per row: the best of the slices' winners.
+// Per row: the best of n_split winners (winner s of row r at winners[r * row_stride + s * split_stride]), as a token id
+// and / or as the winning key itself.
 __global__ __launch_bounds__(256) void sample_finish_kernel(const unsigned long long* __restrict__ winners, int n_split, int batch,
-                                                            int64_t* __restrict__ out_ids) {
+                                                            int64_t row_stride, int64_t split_stride, int64_t* __restrict__ out_ids,
+                                                            unsigned long long* __restrict__ out_winner) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= batch) return;
     unsigned long long w = 0;
-    for (int s = 0; s < n_split; ++s) { const unsigned long long o = winners[(int64_t)row * n_split + s]; w = o > w ? o : w; }
-    out_ids[row] = w == 0 ? 0 : (int64_t)(0xffffffffu - (uint32_t)(w & 0xffffffffull));
+    for (int s = 0; s < n_split; ++s) { const unsigned long long o = winners[(int64_t)row * row_stride + s * split_stride]; w = o > w ? o : w; }
+    if (out_ids) out_ids[row] = w == 0 ? 0 : (int64_t)(0xffffffffu - (uint32_t)(w & 0xffffffffull));
+    if (out_winner) out_winner[row] = w;
 }
 
 static int sampler_check(const void* logits, int64_t stride, const float* t, const int64_t* k, const float* p, const float* mp,
@@ -910,10 +916,10 @@ extern "C" int nvx_sample(const void* logits, int logits_is_f32, int64_t logits_
     // rows without a filter (and greedy rows), cut into slices ...
     if (logits_is_f32)
         hipLaunchKernelGGL((sample_kernel<true>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, winners, n_split);
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, winners, n_split, 0, (int)vocab);
     else
         hipLaunchKernelGGL((sample_kernel<false>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride,
-                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, winners, n_split);
+                           temperatures, top_ks, top_ps, min_ps, (int)vocab, seed, offset, out_ids, winners, n_split, 0, (int)vocab);
     rc = nvx_check_launch("nvx_sample");
     if (rc) return rc;
     // ... then the filtered rows, one workgroup each (it returns at once on a row the first kernel drew)
@@ -928,8 +934,58 @@ extern "C" int nvx_sample(const void* logits, int logits_is_f32, int64_t logits_
                                              (int)vocab, seed, offset, out_ids, nullptr, winners, n_split);
     rc = nvx_check_launch("nvx_sample(filtered rows)");
     if (rc || !ws) return rc;
-    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, winners, n_split, (int)batch, out_ids);
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, winners, n_split, (int)batch,
+                       (int64_t)n_split, (int64_t)1, out_ids, (unsigned long long*)nullptr);
     return nvx_check_launch("nvx_sample(finish)");
+}
+
+// One tensor-parallel rank's part of a sampling step whose rows have no filter: the draw over this rank's shard of the
+// vocabulary, left as one 64-bit (score, token) key per row.  The largest key over the ranks is the token nvx_sample
+// draws from the gathered row (same noise per token, same tie rule), so the ranks exchange 8 bytes per row instead of
+// their logits.
+extern "C" int nvx_sample_shard(const void* logits, int logits_is_f32, int64_t logits_row_stride, const float* temperatures,
+                                int64_t batch, int64_t shard_vocab, int64_t vocab_offset, int64_t vocab, uint64_t seed,
+                                uint64_t offset, uint64_t* winner_out, void* ws, int64_t ws_bytes, nvx_stream_t stream) {
+    NVX_REQUIRE(batch >= 0 && shard_vocab > 0 && vocab_offset >= 0 && vocab > 0, NVX_EINVAL, "nvx_sample_shard: bad size");
+    if (batch == 0) return NVX_OK;
+    NVX_REQUIRE(logits && temperatures && winner_out && ws, NVX_EINVAL, "nvx_sample_shard: null pointer");
+    NVX_REQUIRE(batch <= 65535 && vocab_offset + shard_vocab <= 0x7fffffffll && vocab <= 0x7fffffffll, NVX_EUNSUPPORTED,
+                "nvx_sample_shard: more than 65535 rows or token ids beyond 2^31");
+    NVX_REQUIRE(vocab_offset % 4 == 0, NVX_EINVAL, "nvx_sample_shard: a shard must start at a multiple of 4 tokens (four tokens share a noise block)");
+    NVX_REQUIRE(logits_row_stride >= shard_vocab, NVX_EINVAL, "nvx_sample_shard: row stride smaller than the shard");
+    NVX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0 && (reinterpret_cast<uintptr_t>(winner_out) & 7u) == 0, NVX_EINVAL,
+                "nvx_sample_shard: workspace and output must be 8-byte aligned");
+    int n_split = (int)(512 / batch);
+    n_split = n_split < 1 ? 1 : (n_split > SMP_MAX_SPLIT ? SMP_MAX_SPLIT : n_split);
+    NVX_REQUIRE(ws_bytes >= batch * n_split * 8, NVX_ENOSPACE, "nvx_sample_shard: workspace too small (%lld < %lld bytes)",
+                (long long)ws_bytes, (long long)(batch * n_split * 8));
+    unsigned long long* winners = (unsigned long long*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n_split, (unsigned)batch);
+    const int64_t* none_k = nullptr;
+    const float* none_f = nullptr;
+    if (logits_is_f32)
+        hipLaunchKernelGGL((sample_kernel<true>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride, temperatures, none_k, none_f,
+                           none_f, (int)shard_vocab, seed, offset, (int64_t*)nullptr, winners, n_split, (int)vocab_offset, (int)vocab);
+    else
+        hipLaunchKernelGGL((sample_kernel<false>), grid, dim3(SMP_THREADS), 0, st, logits, logits_row_stride, temperatures, none_k, none_f,
+                           none_f, (int)shard_vocab, seed, offset, (int64_t*)nullptr, winners, n_split, (int)vocab_offset, (int)vocab);
+    int rc = nvx_check_launch("nvx_sample_shard");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, winners, n_split, (int)batch,
+                       (int64_t)n_split, (int64_t)1, (int64_t*)nullptr, (unsigned long long*)winner_out);
+    return nvx_check_launch("nvx_sample_shard(finish)");
+}
+
+// The token of every row from the ranks' keys: winners is (n_sets, batch), set by set (what an all-gather of the
+// ranks' nvx_sample_shard outputs gives).
+extern "C" int nvx_sample_pick(const uint64_t* winners, int64_t n_sets, int64_t batch, int64_t* out_ids, nvx_stream_t stream) {
+    NVX_REQUIRE(batch >= 0 && n_sets >= 1 && n_sets <= 4096, NVX_EINVAL, "nvx_sample_pick: bad size");
+    if (batch == 0) return NVX_OK;
+    NVX_REQUIRE(winners && out_ids, NVX_EINVAL, "nvx_sample_pick: null pointer");
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)winners, (int)n_sets, (int)batch, (int64_t)1, batch, out_ids, (unsigned long long*)nullptr);
+    return nvx_check_launch("nvx_sample_pick");
 }
 
 extern "C" int nvx_sampler_probs(const void* logits, int logits_is_f32, int64_t logits_row_stride, const float* temperatures,

@@ -255,6 +255,21 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     return out.movedim(0, -2).reshape(x.shape[:-1] + (_TP_SIZE * x.shape[-1],))
 
 
+def tp_all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """(n,) from every rank of the TP group -> (tp, n), rank by rank."""
+    if _TP_SIZE == 1 and not _FORCED:
+        return x.view(1, -1)
+    x = x.contiguous()
+    n = max(_TP_SIZE, 1)
+    if _via_host(x):
+        h = torch.empty(n * x.numel(), dtype=x.dtype)
+        dist.all_gather_into_tensor(h, x.view(-1).cpu(), group=_TP_GROUP)
+        return h.to(x.device).view(n, -1)
+    out = torch.empty(n * x.numel(), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.view(-1), group=_TP_GROUP)
+    return out.view(n, -1)
+
+
 def tp_broadcast(x: torch.Tensor, src: int = 0) -> torch.Tensor:
     """Broadcast within this stage's TP group; `src` is the TP rank of the sender."""
     if _TP_SIZE > 1:

@@ -40,3 +40,15 @@ class Sampler(nn.Module):
         self.calls += 1
         return ops.sample(logits, temperatures.float().flatten(), top_ks.to(torch.int64).flatten(), top_ps.float().flatten(),
                           min_ps.float().flatten(), self.seed, self.calls, out=out)
+
+    def forward_shard(self, logits: torch.Tensor, temperatures: torch.Tensor, vocab_offset: int, vocab: int) -> torch.Tensor:
+        """A tensor-parallel rank's part of a step whose rows have no filter: the draw over this rank's shard of the
+        vocabulary as one 64-bit key per row (int64 bit patterns); `ops.sample_pick` over the ranks' keys gives the
+        token `forward` would draw from the gathered row.  Counts as one call, like `forward`, so the ranks' and the
+        gathered path's (seed, counter) pairs stay the same."""
+        if logits.dtype == torch.float16:
+            logits = logits.float()
+        if logits.stride(-1) != 1:
+            logits = logits.contiguous()
+        self.calls += 1
+        return ops.sample_shard(logits, temperatures.float().flatten(), vocab_offset, vocab, self.seed, self.calls)

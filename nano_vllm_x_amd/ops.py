@@ -388,6 +388,41 @@ def sample(logits, temperatures, top_ks, top_ps, min_ps, seed: int, offset: int,
     return out
 
 
+def sample_shard(logits, temperatures, vocab_offset: int, vocab: int, seed: int, offset: int, out=None, ws=None):
+    """One tensor-parallel rank's part of an unfiltered sampling step: the draw over its shard of the vocabulary
+    (logits (B, shard), token j = token vocab_offset + j of the whole row), one 64-bit (score, token) key per row."""
+    _dev(logits, temperatures)
+    _need(logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (BF16, torch.float32), "sample_shard: logits layout")
+    b, v = logits.shape
+    _need(temperatures.dtype == torch.float32 and temperatures.numel() == b and temperatures.is_contiguous(), "sample_shard: temperatures")
+    _need(vocab_offset >= 0 and vocab_offset % 4 == 0 and vocab > 0, "sample_shard: the shard must start at a multiple of 4 tokens")
+    if ws is None:
+        ws = sample_workspace(b, logits.device)
+    if out is None:
+        out = torch.empty((b,), dtype=torch.int64, device=logits.device)
+    else:
+        _need(out.dtype == torch.int64 and out.numel() >= b and out.is_contiguous(), "sample_shard: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_sample_shard(_ptr(logits), int(logits.dtype == torch.float32), logits.stride(0), _ptr(temperatures), b, v,
+                                    vocab_offset, vocab, seed & (2**64 - 1), offset & (2**64 - 1), _ptr(out), _ptr(ws), ws.numel() * 8,
+                                    _stream()), "nvx_sample_shard")
+    return out
+
+
+def sample_pick(winners, out=None):
+    """Token ids from the ranks' keys: winners (n_sets, B) int64 (bit patterns of the 64-bit keys) -> (B,) int64."""
+    _dev(winners)
+    _need(winners.dim() == 2 and winners.dtype == torch.int64 and winners.is_contiguous(), "sample_pick: winners must be contiguous int64 (sets, B)")
+    n, b = winners.shape
+    if out is None:
+        out = torch.empty((b,), dtype=torch.int64, device=winners.device)
+    else:
+        _need(out.dtype == torch.int64 and out.numel() >= b and out.is_contiguous(), "sample_pick: out")
+    lib = _lib.load()
+    _lib.check(lib.nvx_sample_pick(_ptr(winners), n, b, _ptr(out), _stream()), "nvx_sample_pick")
+    return out
+
+
 def sampler_probs(logits, temperatures, top_ks, top_ps, min_ps):
     """The distribution the sampler draws from (after temperature, top-k, top-p, min-p), fp32 (B, V)."""
     b, v = _sampler_args(logits, temperatures, top_ks, top_ps, min_ps)

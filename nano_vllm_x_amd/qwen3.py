@@ -364,6 +364,10 @@ class Qwen3ForCausalLM(nn.Module):
         logits = tpd.tp_all_gather_last_dim(F.linear(hidden_states, self.lm_head.weight))
         return logits[..., :self.config.vocab_size]
 
+    def compute_logits_shard(self, hidden_states: torch.Tensor):
+        """This rank's columns of the logits, not gathered: ((B, vocab / tp) logits, id of their first token)."""
+        return F.linear(hidden_states, self.lm_head.weight), self.lm_head.start
+
     # -- weights ---------------------------------------------------------------------------------
     @torch.no_grad()
     def init_random(self, seed: int = 0):

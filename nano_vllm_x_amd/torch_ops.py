@@ -23,6 +23,8 @@ _DEFS = {
     "silu_mul": "(Tensor x) -> Tensor",
     "sample": "(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps, int seed, int offset) -> Tensor",
     "sampler_probs": "(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps) -> Tensor",
+    "sample_shard": "(Tensor logits, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset) -> Tensor",
+    "sample_pick": "(Tensor winners) -> Tensor",
     "qknorm_rope_store": "(Tensor qkv, Tensor positions, Tensor cos_sin, Tensor q_weight, Tensor k_weight, float eps, Tensor slots, "
                          "Tensor(a!) k_cache, Tensor(b!) v_cache, int n_q_heads, int n_kv_heads) -> Tensor",
     # paged attention, decode: plan once per step, then one call per layer
@@ -84,6 +86,14 @@ def _sample(logits, temperatures, top_ks, top_ps, min_ps, seed, offset):
 
 def _sampler_probs(logits, temperatures, top_ks, top_ps, min_ps):
     return ops.sampler_probs(logits, temperatures, top_ks, top_ps, min_ps)
+
+
+def _sample_shard(logits, temperatures, vocab_offset, vocab, seed, offset):
+    return ops.sample_shard(logits, temperatures, vocab_offset, vocab, seed, offset)
+
+
+def _sample_pick(winners):
+    return ops.sample_pick(winners)
 
 
 def _qknorm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, slots, k_cache, v_cache, n_q_heads, n_kv_heads):

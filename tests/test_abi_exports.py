@@ -105,7 +105,8 @@ def test_every_kernel_entry_point_has_a_custom_op():
              "nvx_decode_plan": "decode_plan", "nvx_paged_decode": "paged_decode", "nvx_paged_decode_qkv": "paged_decode_qkv",
              "nvx_paged_decode_noalloc": "paged_decode_noalloc", "nvx_prefill_plan": "prefill_plan", "nvx_paged_prefill": "paged_prefill",
              "nvx_sample": "sample", "nvx_sampler_probs": "sampler_probs", "nvx_block_table_write_rows": "block_table_write_rows",
-             "nvx_decode_step_setup": "decode_step_setup", "nvx_peer_allreduce_norm": "peer_allreduce_norm"}
+             "nvx_decode_step_setup": "decode_step_setup", "nvx_peer_allreduce_norm": "peer_allreduce_norm",
+             "nvx_sample_shard": "sample_shard", "nvx_sample_pick": "sample_pick"}
     helpers = {"nvx_abi_version", "nvx_last_error", "nvx_linear_decode_splits", "nvx_decode_plan_ws_ints", "nvx_decode_partial_ws_floats",
                "nvx_prefill_plan_ws_ints", "nvx_sample_ws_bytes", "nvx_paged_decode_noalloc_max_batch",
                # start-up calls of the direct-peer exchange (allocation, handle exchange, status, teardown): host side

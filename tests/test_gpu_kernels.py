@@ -474,6 +474,38 @@ def test_torch_ops_namespace_calls_the_same_kernels(ops):
         torch.ops.nvx.silu_mul(x.cpu())   # no CPU kernel is registered
 
 
+@pytest.mark.parametrize("v,f32", [(151936, False), (151936, True), (1000, False), (50257, False)])
+def test_sharded_sampling_draws_the_token_of_the_gathered_row(ops, v, f32):
+    """Tensor-parallel ranks draw over their own shards of the (64-padded) vocabulary and exchange one 64-bit key per
+    row; the largest key must be the token nvx_sample draws from the whole row -- same noise per token, same tie
+    rule -- for sampled rows at several temperatures and for a greedy row, with 2, 4 and 8 shards."""
+    import nano_vllm_x_amd.torch_ops  # noqa: F401  (registers torch.ops.nvx.*)
+
+    gen = torch.Generator().manual_seed(31)
+    b = 37
+    padded = (v + 63) // 64 * 64
+    full = torch.zeros(b, padded)
+    full[:, :v] = torch.randn(b, v, generator=gen) * 2
+    full[5, :v] = 0.0                                   # a row of ties: the lowest token id among the best scores wins
+    logits = (full if f32 else full.to(torch.bfloat16)).to(DEV)
+    t = (0.3 + torch.rand(b, generator=gen)).to(DEV)
+    t[3] = 0.0                                          # greedy
+    k = torch.full((b,), v, dtype=torch.int64, device=DEV)
+    p = torch.ones(b, device=DEV)
+    mp = torch.zeros(b, device=DEV)
+    for seed, offset in ((77, 5), (3, 1234567)):
+        want = ops.sample(logits[:, :v], t, k, p, mp, seed, offset).cpu()
+        for tp in (2, 4, 8):
+            per = padded // tp
+            keys = torch.stack([ops.sample_shard(logits[:, r * per:(r + 1) * per], t, r * per, v, seed, offset) for r in range(tp)])
+            got = ops.sample_pick(keys).cpu()
+            assert torch.equal(got, want), f"{tp} shards: {(got != want).sum().item()} of {b} rows differ"
+            assert int(got.max()) < v
+        via_op = torch.ops.nvx.sample_pick(torch.stack([torch.ops.nvx.sample_shard(logits[:, r * (padded // 2):(r + 1) * (padded // 2)], t,
+                                                                                    r * (padded // 2), v, seed, offset) for r in range(2)]))
+        assert torch.equal(via_op.cpu(), want)
+
+
 def test_sampler_sliced_rows_draw_the_same_tokens(ops):
     """With a workspace, unfiltered rows are cut into slices over several workgroups; the draw must be the
     token the one-workgroup path draws, and filtered rows in the same batch must be unaffected."""

@@ -172,9 +172,10 @@ def test_tensor_parallel_decode_graph_with_direct_peer_allreduce():
 
 
 # -- run-ahead on tensor-parallel ranks -----------------------------------------------------------------
-def _run_tp_engine(rank, tp, port, q, run_ahead):
+def _run_tp_engine(rank, tp, port, q, run_ahead, sample_mode="shard"):
     try:
         os.environ["NVX_PEER_AR"] = "1"
+        os.environ["NVX_TP_SAMPLE"] = sample_mode
         from nano_vllm_x_amd import distributed as tpd
         from nano_vllm_x_amd.core.common import SamplingParams
         from nano_vllm_x_amd.core.engine import Engine
@@ -205,18 +206,20 @@ def _run_tp_engine(rank, tp, port, q, run_ahead):
         q.put((rank, None, traceback.format_exc()))
 
 
-def test_run_ahead_on_tensor_parallel_ranks_generates_the_same_streams():
+def test_sharded_sampling_and_run_ahead_on_tensor_parallel_ranks_generate_the_same_streams():
     """Two ranks, decode steps replayed from the graph with direct-peer all-reduces inside, step N+1 queued before
     step N's ids have reached the host: the decision to queue ahead depends on the scheduler's state alone, which
     is the same on every rank, so the ranks stay in lockstep and the sampled streams equal those without it."""
     runs = {}
-    for ra in (False, True):
+    # the reference's way (gather the logits, sample whole rows, broadcast the ids), then each rank drawing over its own
+    # shard of the vocabulary, then that with run-ahead: the sampled streams must be the same in all three
+    for ra, mode in ((False, "gather"), (False, "shard"), (True, "shard")):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=_run_tp_engine, args=(r, 2, port, q, ra)) for r in range(2)]
+        procs = [ctx.Process(target=_run_tp_engine, args=(r, 2, port, q, ra, mode)) for r in range(2)]
         for p in procs:
             p.start()
         res = {}
@@ -229,10 +232,13 @@ def test_run_ahead_on_tensor_parallel_ranks_generates_the_same_streams():
         assert res[0][0] == res[1][0], "ranks generated different tokens"
         for k, n in res[0][1].items():
             assert len(res[0][0][k]) == n
-        runs[ra] = res[0]
-    assert runs[True][0] == runs[False][0], "run-ahead changed the sampled streams"
-    assert runs[True][3] > 0 and runs[False][3] == 0
-    assert runs[True][2]["graph_steps"] > 0 and runs[True][2]["eager_decode_steps"] == 0
+        runs[(ra, mode)] = res[0]
+    base, shard, ahead = runs[(False, "gather")], runs[(False, "shard")], runs[(True, "shard")]
+    assert shard[0] == base[0], "sampling over vocabulary shards changed the sampled streams"
+    assert ahead[0] == base[0], "run-ahead changed the sampled streams"
+    assert ahead[3] > 0 and base[3] == 0 and shard[3] == 0
+    assert ahead[2]["graph_steps"] > 0 and ahead[2]["eager_decode_steps"] == 0
+    assert base[2].get("sharded_sampling_steps", 0) == 0 and shard[2]["sharded_sampling_steps"] > 0 and ahead[2]["sharded_sampling_steps"] > 0
 
 
 # -- several batches in flight across the stages --------------------------------------------------
