@@ -295,8 +295,11 @@ class ModelRunner:
             out = self._sample_hosts[ids][:n].tolist()
         else:
             out = ids.tolist()
-        tpd.check_peer_status()      # a direct-peer exchange that gave up waiting must not pass as a result
         key = "decode_s" if batch.forward_mode == ForwardMode.DECODE else "prefill_s"
+        try:
+            tpd.check_peer_status()      # a direct-peer exchange that gave up waiting must not pass as a result
+        except RuntimeError as e:
+            raise RuntimeError(f"{e} [rank {self.rank}, {key[:-2]} step of {n} sequences, steps so far {self.stats}]") from None
         # launch to completion; a step queued behind another is charged from the moment that one completed
         now = time.perf_counter()
         self.stats[key] = self.stats.get(key, 0.0) + (now - max(t0, self._last_done))

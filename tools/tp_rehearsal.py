@@ -5,6 +5,12 @@ gloo (NVX_TP_BACKEND=gloo), a small Qwen3 geometry, the LLM.generate pump.
   NVX_TP_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
       --master-addr 127.0.0.1 --master-port 29513 tools/tp_rehearsal.py
   NVX_PP=2 ... --nproc-per-node 4 ...     # two stages of two tensor-parallel ranks
+
+bench.py runs the same way (NVX_TP_BACKEND=gloo python -m torch.distributed.run ... bench.py --gpus N --num-seqs 48
+--max-bs 128 --kv-cache-size 200000 --no-roofline --no-cpu-baseline).  With ranks SHARING a GPU and decode batches of
+112 rows or more, also set NVX_LIN_GATEUP_WIDE_MIN=100000: the 64-row gate/up projection takes whole SIMDs' registers and
+cannot be placed while the other ranks' all-reduce kernels wait on every CU for this rank (on separate GPUs they never
+share a chip).
 """
 import asyncio, hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
