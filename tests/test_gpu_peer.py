@@ -97,6 +97,16 @@ def _peer_worker(rank, tp, port, q, dtype_name, hidden):
             digest.append(y.cpu())
         assert group.status() == 0
 
+        # rows that are not contiguous (a column view of a wider tensor, as a fused projection's output may be)
+        wide = torch.zeros(9, 2 * hidden, dtype=dtype, device=dev)
+        wide[:, hidden:] = _inputs(300, rank, 9, hidden, dtype).to(dev)
+        view = wide[:, hidden:]
+        assert view.stride(0) == 2 * hidden
+        y_v = ops.peer_allreduce_norm(group, view, weight, EPS)
+        want_v = ops.rmsnorm_splitk(_expected_sum(300, tp, 9, hidden, dtype).to(dev).float()[None].contiguous(), weight, EPS)
+        assert torch.equal(y_v, want_v), "strided rows: norm differs"
+        digest.append(y_v.cpu())
+
         # a chain of exchanges captured in a graph and replayed: the tags advance on the device
         x0 = _inputs(500, rank, 16, hidden, dtype).to(dev)
         res0 = _inputs(501, 99, 16, hidden, dtype).to(dev)

@@ -73,6 +73,15 @@ def _case_collectives(rank: int):
     ids = torch.tensor([5, 6, 7]) if rank == 0 else torch.zeros(3, dtype=torch.int64)
     assert tpd.tp_broadcast(ids).tolist() == [5, 6, 7]
     assert tpd.tp_all_gather_min_int(1000 - 10 * rank, "cpu") == 990
+    # the ranks' per-row keys of a sharded sampling step, rank by rank
+    keys = torch.tensor([10 * rank + 1, 10 * rank + 2, 10 * rank + 3], dtype=torch.int64)
+    assert tpd.tp_all_gather_rows(keys).tolist() == [[1, 2, 3], [11, 12, 13]]
+    # without a GPU there is no direct-peer exchange: it reports so, and a row-parallel output is reduced at once
+    assert tpd.init_peer_allreduce(8, 64, torch.bfloat16, "cpu") is False and not tpd.peer_allreduce_active()
+    y = tpd.tp_reduce_later(torch.full((2, 64), float(rank + 1)))
+    assert isinstance(y, torch.Tensor) and torch.equal(y, torch.full((2, 64), 3.0))
+    assert tpd.tp_finish_reduce(y) is y
+    tpd.check_peer_status()        # nothing to report
 
 
 def test_collective_wrappers():
