@@ -158,8 +158,12 @@ def decode_attention_roofline(runner, batches, reps: int = 14):
         launches += reps
     achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("paged_decode_kernel"),
-            "kernel": "paged_decode_kernel<2,2,true> (nvx_paged_decode_qkv) + decode_merge_kernel", "launches": launches,
+            # the counter passes were taken on the default geometry (16 query / 8 kv heads per rank): no figure for another
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": _pmc_traffic("paged_decode_kernel") if (runner.num_heads, runner.num_kv_heads) == (16, 8) else None,
+            "kernel": f"nvx_paged_decode_qkv ({runner.num_heads} query / {runner.num_kv_heads} kv heads"
+                      + (": paged_decode_kernel<2,2,true>" if (runner.num_heads, runner.num_kv_heads) == (16, 8) else "")
+                      + ") + decode_merge_kernel", "launches": launches,
             "avg_launch_us": round(total_ms * 1e3 / max(1, launches), 2),
             "avg_algorithmic_bytes": int(total_bytes / max(1, launches))}
 
@@ -216,8 +220,10 @@ def prefill_attention_roofline(runner, prompts, reps: int = 8):
     compulsory = total * (2 * hq * 256 + 2 * hkv * 256) + 4 * total
     attainable = min(MFMA_BF16_PEAK_TFLOPS, flop / (compulsory / (HBM_PEAK_GBS * 1e9)) / 1e12)
     return {"bound": "mfma", "achieved": round(flop / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _pmc_prefill_traffic(),
-            "kernel": "paged_prefill_kernel<2,4> (nvx_paged_prefill)", "launches": reps,
+            "frac": round(flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": _pmc_prefill_traffic() if (hq, hkv) == (16, 8) else None,
+            "kernel": f"nvx_paged_prefill ({hq} query / {hkv} kv heads" + (": paged_prefill_kernel<2,4>" if (hq, hkv) == (16, 8) else "") + ")",
+            "launches": reps,
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops": flop,
             "compulsory_bytes": compulsory, "flop_per_byte": round(flop / compulsory, 1),
             "hbm_floor_us": round(compulsory / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
