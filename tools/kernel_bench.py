@@ -91,7 +91,21 @@ def cmd_decode(args):
         idx = torch.from_numpy(flat).to(DEV)
         q = torch.randn(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
         out = torch.empty_like(q)
-        if args.qkv:   # the variant fed with the raw fused projection (norm + rotary + scatter inside)
+        if args.unfused:   # what the fused variant replaces: the q/k-norm + rotary + scatter kernel, then attention on finished queries
+            from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
+            qkv = torch.randn(b, (HQ + 2 * HKV) * 128, device=DEV, dtype=torch.bfloat16)
+            pos = (kv_len - 1).to(torch.int64)
+            new_slots = idx[(kv_start + kv_len - 1)].to(torch.int64)
+            table = build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+            nw = torch.ones(128, device=DEV, dtype=torch.bfloat16)
+            qbuf = torch.empty(b, HQ * 128, device=DEV, dtype=torch.bfloat16)
+            ops.decode_plan(kv_len, kv_start, ws)
+
+            def run():
+                ops.qknorm_rope_store(qkv, pos, table, nw, nw, 1e-6, new_slots, kc[layer[0]], vc[layer[0]], HQ, HKV, q_out=qbuf)
+                ops.paged_decode(qbuf, kc[layer[0]], vc[layer[0]], idx, b, ws, 128 ** -0.5, out=out)
+                layer[0] = (layer[0] + 1) % layers
+        elif args.qkv:   # the variant fed with the raw fused projection (norm + rotary + scatter inside)
             from nano_vllm_x_amd.layers.rotary_embedding import build_cos_sin_cache
             qkv = torch.randn(b, (HQ + 2 * HKV) * 128, device=DEV, dtype=torch.bfloat16)
             pos = (kv_len - 1).to(torch.int64)
@@ -245,6 +259,7 @@ if __name__ == "__main__":
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--hkv1", action="store_true")
     ap.add_argument("--qkv", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="decode: q/k-norm + rotary + scatter kernel followed by attention on finished queries")
     ap.add_argument("--uniform-len", type=int, default=0)
     ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
