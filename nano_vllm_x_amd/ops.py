@@ -504,9 +504,15 @@ class PeerGroup:
             _lib.check(_lib.load().nvx_peer_destroy(self.comm), "nvx_peer_destroy")
             self.comm = None
 
+    # Every rank writes its whole tensor to every peer (one hop, no second exchange): the latency of one posted write,
+    # but (tp - 1) x rows x hidden x 4 bytes leave each GPU (2 bytes of tag beside every 2 bytes of data), against
+    # 2 x (tp - 1) / tp x rows x hidden x 2 for a reduce-scatter + all-gather.  Past a few MiB per exchange the links'
+    # time outweighs the saved hops and launches, and the library's bandwidth-oriented all-reduce takes over.
+    MAX_PUSH_BYTES = int(__import__("os").environ.get("NVX_PEER_MAX_PUSH_BYTES", str(4 << 20)))
+
     def fits(self, x) -> bool:
         return self.comm is not None and x.dim() == 2 and x.shape[0] <= self.max_rows and x.shape[1] == self.hidden and x.dtype in H16 \
-            and x.stride(1) == 1
+            and x.stride(1) == 1 and (self.tp_size - 1) * x.shape[0] * self.hidden * 4 <= self.MAX_PUSH_BYTES
 
 
 def peer_allreduce_norm(group: PeerGroup, x, weight=None, eps: float = 0.0, residual=None):
