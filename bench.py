@@ -66,6 +66,31 @@ async def one_pass(llm, prompts, max_tokens):
     return sum(counts)
 
 
+def max_over_ranks(seconds: float, world: int, device) -> float:
+    if world == 1:
+        return seconds
+    # (a rehearsal with several ranks on one GPU talks through gloo: host tensors there)
+    w = torch.tensor([seconds], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else device)
+    torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+    return float(w.item())
+
+
+def decode_step_roofline(runner, kv_rows: int, decode_steps: int, decode_s: float):
+    """The decode steps of one pass as a whole against this rank's HBM: every step must stream this rank's weights once
+    (decoder layers + LM head; the embedding is a gather of B rows) and every listed K and V row of every local layer;
+    `decode_s` is the time the engine's decode steps took (device-bound under run-ahead)."""
+    model = runner.model
+    weights = sum(p.numel() * p.element_size() for p in model.parameters())
+    if not model.config.tie_word_embeddings and hasattr(model.model.embed_tokens, "weight"):
+        weights -= model.model.embed_tokens.weight.numel() * model.model.embed_tokens.weight.element_size()
+    kv = kv_rows * 2 * runner.num_kv_heads * runner.head_dim * runner.dtype.itemsize * runner.num_layers
+    total = kv + weights * decode_steps
+    achieved = total / decode_s / 1e9 if decode_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "kv_bytes_per_pass": kv, "weight_bytes_per_decode_step": weights, "decode_steps_per_pass": decode_steps,
+            "decode_s_per_pass": round(decode_s, 4), "scope": "one rank: all kernels of its decode steps, not only the attention pair"}
+
+
 def sync_all(world: int):
     torch.cuda.synchronize()
     if world > 1:
@@ -358,27 +383,29 @@ def main():
                     help="> 0: admit prompts in prefill steps of at most this many tokens (0 = one step for the burst, as the reference)")
     ap.add_argument("--run-ahead", type=int, default=1,
                     help="1: queue decode step N+1 before step N's ids reach the host (same batches, same tokens on every rank)")
+    ap.add_argument("--plain-pass", type=int, default=1,
+                    help="1: after the timed passes, one more pass with run-ahead off (value_without_run_ahead)")
     ap.add_argument("--cpu-requests", type=int, default=8)
     ap.add_argument("--cpu-new-tokens", type=int, default=48)
     ap.add_argument("--roofline-every", type=int, default=8)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed plainly (`python3 bench.py --gpus N`): start the N ranks as a fresh child job -- this process has made
+        # no GPU call yet and makes none; it waits, lets the ranks' output through and hands their exit code on
+        from nano_vllm_x_amd.launch import run_ranks
+        raise SystemExit(run_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
 
     from nano_vllm_x_amd import LLM
 
     prompts, max_tokens = workload(args.num_seqs)
     t_init = time.perf_counter()
+    # None: sized as the reference does (model_runner.py:160-169) -- the smallest, over all ranks, of
+    # free memory x utilisation / KV bytes per token on that rank
     kv_size = args.kv_cache_size or None
-    if kv_size is None and world > 1:
-        # per-rank KV bytes shrink with TP; keep the slot count of the one-GPU run (0.8 of 288 GB at
-        # 114 688 B per token) instead of letting it grow with the number of ranks
-        kv_size = 2_000_000
     llm = LLM(model=args.model, gpu_memory_utilization=0.8, max_bs=args.max_bs, tp_size=world, pp_size=1,
               context_len=args.context_len, enforce_eager=args.enforce_eager, kv_cache_size=kv_size,
               run_ahead=bool(args.run_ahead), max_prefill_tokens=args.max_prefill_tokens or None)
@@ -397,13 +424,22 @@ def main():
         generated += asyncio.run(one_pass(llm, prompts, max_tokens))
     sync_all(world)
     wall = time.perf_counter() - t0
-    if world > 1:
-        # (a rehearsal with several ranks on one GPU talks through gloo: host tensors there)
-        w = torch.tensor([wall], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else eng.model_runner.device)
-        torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
-        wall = float(w.item())
-    stats1 = eng.model_runner.stats
+    wall = max_over_ranks(wall, world, eng.model_runner.device)
+    stats1 = dict(eng.model_runner.stats)
     nominal = sum(max_tokens) * args.steps
+    ahead_steps_timed = eng.ahead_steps
+    # One more pass with run-ahead off: every step waits for its ids before the next is scheduled, as the reference's
+    # loop does (engine.py:81-100).  Same batches, same tokens; reported beside `value`, never as `value`.
+    plain_wall = None
+    if eng.run_ahead and args.plain_pass:
+        eng.run_ahead = False
+        eng.reset()
+        sync_all(world)
+        t1 = time.perf_counter()
+        asyncio.run(one_pass(llm, prompts, max_tokens))
+        sync_all(world)
+        plain_wall = max_over_ranks(time.perf_counter() - t1, world, eng.model_runner.device)
+        eng.run_ahead = True
     # what ran, not what was asked for: a decode graph that could not be captured (a collective RCCL refuses to
     # capture) leaves the runner on eager decode steps, and the line must say so
     runner = eng.model_runner
@@ -426,7 +462,7 @@ def main():
                                f"temperature 0.6, ignore_eos, all submitted at once, {args.model} geometry",
                    "geometry": args.model, "ranks": f"tp{world}", "max_bs": args.max_bs, "context_len": args.context_len,
                    "kv_cache_slots": eng.kv_cache_size, "decode": decode_mode,
-                   "run_ahead": eng.run_ahead, "steps_queued_ahead": eng.ahead_steps,
+                   "run_ahead": eng.run_ahead, "steps_queued_ahead": ahead_steps_timed,
                    "max_prefill_tokens": args.max_prefill_tokens or None},
         "generated_tokens_per_s": round(generated / wall, 2), "generated_tokens_per_step": generated // max(1, args.steps),
         "nominal_tokens_per_step": sum(max_tokens), "prompt_tokens_per_step": sum(len(p) for p in prompts),
@@ -434,9 +470,16 @@ def main():
         "vs_baseline_note": "reference README: 9032.37 tok/s on 1x A100 40GB (other hardware)",
     }
 
+    if plain_wall is not None:
+        result["value_without_run_ahead"] = round(sum(max_tokens) / plain_wall, 2)
+        result["ms_per_step_without_run_ahead"] = round(plain_wall * 1e3, 2)
     if world > 1:
         from nano_vllm_x_amd import distributed as tpd
         result["config"]["all_reduce"] = tpd.PEER_STATE      # which path the decode-sized all-reduces took
+        result["config"]["backend"] = torch.distributed.get_backend()
+        result["config"]["world_size"] = torch.distributed.get_world_size()
+        result["config"]["hipgraph_decode_steps"], result["config"]["eager_decode_steps"] = graph_steps, eager_steps
+        result["config"]["sharded_sampling_steps"] = stats1.get("sharded_sampling_steps", 0) - stats0.get("sharded_sampling_steps", 0)
     if rank == 0 and not args.no_roofline:
         batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
                                                              args.context_len, args.roofline_every)
@@ -444,6 +487,8 @@ def main():
             result["roofline"] = decode_attention_roofline(eng.model_runner, batches)
         result["roofline"]["sampled_decode_batches"] = f"{len(batches)} of {n_dec} (every {args.roofline_every}th), x14 graph-replayed launches over rotating layers"
         result["decode_kv_rows_per_step"] = kv_rows
+        result["decode_step_roofline"] = decode_step_roofline(
+            runner, kv_rows, n_dec, (stats1["decode_s"] - stats0.get("decode_s", 0.0)) / max(1, args.steps))
         with torch.inference_mode():
             result["roofline_prefill"] = prefill_attention_roofline(eng.model_runner, prompts)
     gpu_c1 = None

@@ -10,6 +10,7 @@ the model and one broadcast of the sampled ids.
 from __future__ import annotations
 
 from collections import deque
+from dataclasses import replace
 from typing import Optional
 
 from .common import EngineOutput, FinishReason, ForwardBatch, SamplingParams, Sequence, SequenceStatus
@@ -34,6 +35,9 @@ class EngineCore:
         if len(prompt_token_ids) > self.context_len:   # keep the tail (engine.py:59-60)
             prompt_token_ids = prompt_token_ids[-self.context_len:]
         n = len(prompt_token_ids)
+        # the engine keeps its own copy of the parameters: the runner caches their device form while a batch holds the
+        # same objects, so a caller that edits its object after submission must not reach a running sequence
+        sampling_params = replace(sampling_params)
         self.scheduler.add_sequence(Sequence(seq_id=sequence_id, token_ids=prompt_token_ids, num_tokens=n,
                                              prompt_len=n, sampling_params=sampling_params))
 

@@ -193,6 +193,7 @@ class ModelRunner:
         `ids_on_device`: the input ids are ids the step before sampled (see launch_step).
         `shard`: return (this rank's columns of the logits, id of their first token) instead of gathering the ranks'."""
         decode = batch.forward_mode == ForwardMode.DECODE
+        tpd.check_peer_status()      # results leave through here too (tests, tools): never on top of a failed exchange
         if self.graph_step_possible(batch):
             hidden = self._execute_model_graph(batch, ids_on_device)
             self.stats["graph_steps"] += 1

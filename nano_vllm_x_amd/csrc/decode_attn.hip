@@ -455,7 +455,7 @@ __device__ __forceinline__ unsigned dec_lds_addr(const void* p) {
 }
 // 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS starting at a wave-uniform address, as a streaming
 // (non-temporal) read.  Issued from inline assembly: the compiler's own LDS-DMA builtin makes every later LDS read wait
-// for the copy.  m0 has no other user in this kernel.
+// for the copy.  m0 has no other user in this kernel: the toolchain refuses m0 in a clobber list (reserved register), so tests/test_abi_exports.py disassembles the library and checks that every access to m0 is one of these moves.
 __device__ __forceinline__ void dec_dma16(const char* g, unsigned lds_addr) {
     const unsigned uni = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(uni) : "memory");
@@ -916,8 +916,15 @@ static int noalloc_scratch(unsigned char** ptr, const char* who) {
     NVX_REQUIRE(dev >= 0 && dev < NVX_MAX_DEVICES, NVX_EUNSUPPORTED, "%s: device ordinal %d outside [0, %d)", who, dev, NVX_MAX_DEVICES);
     std::lock_guard<std::mutex> lock(noalloc_mutex);
     if (!noalloc_ptr[dev]) {
+        // The first call on a device may come from a thread whose stream is being captured into a graph.  The look-up
+        // is no stream operation, but it may load the code object, which a capture in the global or thread-local
+        // mode treats as an error: this thread is switched to the relaxed mode for the look-up alone (what an
+        // allocator that must run under capture does), and back.
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
         void* p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
         if (e != hipSuccess || !p) return nvx_fail(NVX_ELAUNCH, "%s: hipGetSymbolAddress(scratch): %s", who, hipGetErrorString(e));
         noalloc_ptr[dev] = static_cast<unsigned char*>(p);
     }

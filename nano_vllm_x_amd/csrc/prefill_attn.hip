@@ -102,7 +102,7 @@ __device__ __forceinline__ void pf_wait_copies() { asm volatile("s_waitcnt vmcnt
 // barrier that publishes a tile.
 __device__ __forceinline__ void pf_dma16(const unsigned char* g, unsigned lds_addr) {
     // lds_addr is wave-uniform by construction; the explicit broadcast puts it in a scalar register even
-    // where the compiler cannot prove that.  m0 has no other user in this kernel.
+    // where the compiler cannot prove that.  m0 has no other user in this kernel: the toolchain refuses m0 in a clobber list (reserved register), so tests/test_abi_exports.py disassembles the library and checks that every access to m0 is one of these moves.
     const unsigned uni = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(uni) : "memory");
 }

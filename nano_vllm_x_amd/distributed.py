@@ -68,7 +68,11 @@ def init_tensor_parallel(tp_size: int, rank: int | None = None, backend: str | N
         backend = os.environ.get("NVX_TP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         if rank is None:
-            rank = int(os.environ.get("RANK", "0"))
+            # nobody told this process which rank it is: without a launcher's variables it would sit in the
+            # rendezvous below waiting for peers that were never started
+            from .launch import require_launcher
+            require_launcher(world, f"tp_size={tp_size}, pp_size={pp_size}")
+            rank = int(os.environ["RANK"])
         if "MASTER_ADDR" in os.environ and "WORLD_SIZE" in os.environ:
             init_method = "env://"
         else:
@@ -146,10 +150,20 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
         return _PEER is not None
     tp, rank = max(_TP_SIZE, 1), _TP_RANK
     group, err = None, None
+    # one routing limit for the whole group (a rank that read another NVX_PEER_MAX_PUSH_BYTES would send a tensor through
+    # the library while its peers wait for it in the exchange kernel): the smallest any rank holds
+    push = ops.PeerGroup.MAX_PUSH_BYTES
+    if tp > 1:
+        pushes = [None] * tp
+        dist.all_gather_object(pushes, push, group=_TP_GROUP)
+        push = min(pushes)
+    # the landing buffer is sized for the rows that will ever take this path: the decode batch, capped by the limit above
+    rows_cap = min(max(max_rows, 1), 512, ops.PeerGroup.rows_within_push_cap(tp, hidden, push))
     try:
         if tp > 8:
             raise RuntimeError("more than 8 ranks")
-        group = ops.PeerGroup(tp, rank, min(max(max_rows, 1), 512), hidden, int(os.environ.get("NVX_PEER_TIMEOUT_MS", "0")))
+        group = ops.PeerGroup(tp, rank, rows_cap, hidden, int(os.environ.get("NVX_PEER_TIMEOUT_MS", "0")))
+        group.max_push_bytes = push
         handle = group.export_handle() if tp > 1 else b""
     except RuntimeError as e:      # every rank still takes part in the exchange below, so nobody waits for a rank that failed
         err, handle = str(e), None
@@ -162,8 +176,8 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
             for p in range(tp):
                 if p != rank:
                     group.import_handle(p, handles[p])
-            # 32 exchanges of full height on data every rank can derive by itself (small integers: sums are exact in
-            # both 16-bit formats), so that both slot parities are reused many times; a few milliseconds in all
+            # 32 exchanges at the group's full height on data every rank can derive by itself (small integers: sums are
+            # exact in both 16-bit formats), so that both slot parities are reused many times; a few milliseconds in all
             rows = group.max_rows
             base = torch.arange(rows * hidden, device=device).view(rows, hidden)
             for it in range(32):
@@ -182,7 +196,9 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
         oks = [None] * tp
         dist.all_gather_object(oks, err is None, group=_TP_GROUP)
     if all(oks):
-        _PEER, PEER_STATE = group, f"direct-peer ({tp} ranks, {group.exchange_bytes >> 20} MiB landing buffer per rank)"
+        _PEER = group
+        PEER_STATE = (f"direct-peer ({tp} ranks, exchanges of up to {group.max_rows} rows x {hidden}, "
+                      f"{max(group.exchange_bytes >> 10, 1)} KiB landing buffer per rank; taller ones: library all-reduce)")
         return True
     if group is not None:
         group.close()
@@ -206,7 +222,7 @@ def check_peer_status():
 def tp_reduce_later(x: torch.Tensor):
     """All-reduce of a row-parallel projection's output -- left to the RMSNorm that follows (Unreduced) when the
     direct-peer exchange can take the tensor, done now otherwise."""
-    if _PEER is not None and _PEER.fits(x):
+    if _PEER is not None and _PEER.prefer(x):
         return Unreduced(x)
     return tp_all_reduce(x)
 
@@ -228,7 +244,7 @@ def peer_allreduce_norm(x: Unreduced, weight: torch.Tensor, eps: float, residual
 
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     if _TP_SIZE > 1 or _FORCED:
-        if _PEER is not None and x.is_contiguous() and _PEER.fits(x):
+        if _PEER is not None and x.is_contiguous() and _PEER.prefer(x):
             torch.ops.nvx.peer_allreduce(_PEER.comm, x)
         elif _via_host(x):
             h = x.float().cpu() if x.dtype == torch.bfloat16 else x.cpu()

@@ -47,6 +47,15 @@ class LLM:
                  enforce_eager: bool = False, context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0,
                  prefix_reuse: bool = False, max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False,
                  chunked_prefill: bool = False, run_ahead: bool = False):
+        if tp_size * pp_size > 1:
+            # The reference spawns its worker processes here (core/executor.py:32-49).  This engine is SPMD: the
+            # caller's script runs once per GPU (launch.run_ranks / torch.distributed.run).  A process that was not
+            # started as a rank is told so now, before any model or device work, not after a rendezvous time-out.
+            import torch.distributed as dist
+
+            from .launch import require_launcher
+            if not dist.is_initialized():
+                require_launcher(tp_size * pp_size, f"LLM(tp_size={tp_size}, pp_size={pp_size})")
         self.engine = Engine(model, gpu_memory_utilization, max_bs, tp_size, pp_size, nccl_port, device_ids,
                              enforce_eager, context_len, kv_cache_size=kv_cache_size, seed=seed, prefix_reuse=prefix_reuse,
                              max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len,

@@ -508,11 +508,27 @@ class PeerGroup:
     # but (tp - 1) x rows x hidden x 4 bytes leave each GPU (2 bytes of tag beside every 2 bytes of data), against
     # 2 x (tp - 1) / tp x rows x hidden x 2 for a reduce-scatter + all-gather.  Past a few MiB per exchange the links'
     # time outweighs the saved hops and launches, and the library's bandwidth-oriented all-reduce takes over.
+    # This is a ROUTING policy (`prefer`), not a limit of the kernel (`accepts`); the ranks of a group must route alike,
+    # so distributed.init_peer_allreduce agrees on one value for all of them (`max_push_bytes`).
     MAX_PUSH_BYTES = int(__import__("os").environ.get("NVX_PEER_MAX_PUSH_BYTES", str(4 << 20)))
 
-    def fits(self, x) -> bool:
+    @staticmethod
+    def rows_within_push_cap(tp_size: int, hidden: int, max_push_bytes: int) -> int:
+        """Most rows of one exchange whose pushes stay within `max_push_bytes` per GPU (at least one)."""
+        return max(1, max_push_bytes // (max(tp_size - 1, 1) * hidden * 4))
+
+    max_push_bytes = MAX_PUSH_BYTES
+
+    def accepts(self, x) -> bool:
+        """What the kernel can take at all: the group's row width and format, at most the rows its landing buffer holds."""
         return self.comm is not None and x.dim() == 2 and x.shape[0] <= self.max_rows and x.shape[1] == self.hidden and x.dtype in H16 \
-            and x.stride(1) == 1 and (self.tp_size - 1) * x.shape[0] * self.hidden * 4 <= self.MAX_PUSH_BYTES
+            and x.stride(1) == 1
+
+    def prefer(self, x) -> bool:
+        """Whether this exchange should go peer to peer rather than through the library all-reduce."""
+        return self.accepts(x) and (self.tp_size - 1) * x.shape[0] * self.hidden * 4 <= self.max_push_bytes
+
+    fits = prefer     # (older name)
 
 
 def peer_allreduce_norm(group: PeerGroup, x, weight=None, eps: float = 0.0, residual=None):
@@ -520,7 +536,7 @@ def peer_allreduce_norm(group: PeerGroup, x, weight=None, eps: float = 0.0, resi
     `residual`).  Returns the sum written over `x` (weight None), y, or (y, new_residual).  Every rank of the group
     must make the same calls in the same order."""
     _dev(x, weight, residual)
-    _need(group.fits(x), f"peer_allreduce_norm: x {tuple(x.shape)} {x.dtype} does not fit the group ({group.max_rows} rows x {group.hidden})")
+    _need(group.accepts(x), f"peer_allreduce_norm: x {tuple(x.shape)} {x.dtype} does not fit the group ({group.max_rows} rows x {group.hidden})")
     rows, hidden = x.shape
     lib = _lib.load()
     if weight is None:

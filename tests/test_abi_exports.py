@@ -118,3 +118,36 @@ def test_every_kernel_entry_point_has_a_custom_op():
     assert set(declared_symbols()) == set(op_of) | helpers | half, set(declared_symbols()) ^ (set(op_of) | helpers | half)
     for sym, op in op_of.items():
         assert hasattr(torch.ops.nvx, op), f"{sym} has no torch.ops.nvx.{op}"
+
+
+def test_the_only_users_of_m0_in_the_device_code_are_the_lds_dma_copies(tmp_path):
+    """The LDS-DMA copies of the attention kernels set m0 (the LDS destination) from inline assembly, and the toolchain
+    refuses m0 in a clobber list.  That is sound only while the compiler itself keeps nothing in m0 in those kernels:
+    every instruction of the library's gfx950 code that names m0 must be a move issued for such a copy, one per copy."""
+    import shutil
+    import subprocess
+
+    from nano_vllm_x_amd import _lib
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("no llvm-objdump in this image")
+    so = tmp_path / "libnvx_hip.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    code_objects = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert code_objects, "no gfx950 code object found in the library"
+    moves = copies = 0
+    for co in code_objects:
+        text = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        for line in text.splitlines():
+            ins = line.split("//")[0].strip()
+            if not ins or ins.endswith(":"):
+                continue
+            if re.search(r"\bglobal_load_lds_", ins):
+                copies += 1
+            if re.search(r"\bm0\b", ins):
+                assert re.match(r"s_mov_b32 m0, s\d+$", ins), f"m0 is used by something other than an LDS-DMA set-up: {ins}"
+                moves += 1
+    assert copies > 0 and moves == copies, f"{moves} moves to m0 for {copies} LDS-DMA copies"

@@ -225,3 +225,47 @@ def test_a_missing_peer_ends_the_wait_and_raises_the_status_word():
     assert ok0 and ok1
     assert status0 == 1 and status1 == 0
     assert 0.25 <= took0 < 5.0, f"the wait took {took0:.2f} s for a 0.3 s time-out"
+
+
+def _routing_worker(rank, tp, port, q):
+    """bench.py's own configuration at 8 ranks (max_bs 256, hidden 1024): the group must come up, and exchanges route
+    by size -- decode-sized ones peer to peer, taller ones through the library."""
+    try:
+        from nano_vllm_x_amd import distributed as tpd
+
+        torch.cuda.set_device(0)
+        tpd.init_tensor_parallel(tp, rank=rank, backend="gloo", port=port)
+        dev = torch.device("cuda", 0)
+        ok = tpd.init_peer_allreduce(256, HIDDEN, torch.bfloat16, dev)
+        state = tpd.PEER_STATE
+        group = tpd._PEER
+        facts = {"ok": ok, "state": state}
+        if ok:
+            cap = 4 * 1024 * 1024 // ((tp - 1) * HIDDEN * 4)
+            facts["max_rows"], facts["cap"] = group.max_rows, cap
+            small = torch.full((29, HIDDEN), float(rank + 1), dtype=torch.bfloat16, device=dev)
+            tall = torch.full((256, HIDDEN), float(rank + 1), dtype=torch.bfloat16, device=dev)
+            a = tpd.tp_reduce_later(small)
+            b = tpd.tp_reduce_later(tall)
+            facts["small_is_deferred"] = isinstance(a, tpd.Unreduced)
+            facts["tall_is_reduced_now"] = torch.is_tensor(b) and bool((b == tp * (tp + 1) // 2).all())
+            summed = tpd.tp_finish_reduce(a)
+            torch.cuda.synchronize()
+            facts["small_sum_ok"] = bool((summed == tp * (tp + 1) // 2).all())
+            facts["accepts_not_prefers"] = (not group.prefer(tall)) and (not group.accepts(tall)) and group.accepts(small)
+            facts["status"] = group.status()
+        tpd.shutdown()
+        q.put((rank, facts, None))
+    except Exception:   # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_the_group_comes_up_at_the_bench_configuration_and_routes_by_size():
+    tp = 8
+    results = _spawn(_routing_worker, tp)
+    for r in range(tp):
+        f = results[r]
+        assert f["ok"] and f["state"].startswith("direct-peer"), f["state"]
+        assert f["max_rows"] == min(256, f["cap"]) == 146
+        assert f["small_is_deferred"] and f["tall_is_reduced_now"] and f["small_sum_ok"] and f["accepts_not_prefers"]
+        assert f["status"] == 0
