@@ -107,7 +107,8 @@ class ModelRunner:
         gc.collect()
         torch.cuda.empty_cache()
         free, _total = torch.cuda.mem_get_info(self.device)
-        n = int(free * gpu_memory_utilization) // per_token
+        # ranks that share a device (rehearsals of several ranks on a one-GPU box) share its free memory too
+        n = int(free * gpu_memory_utilization / tpd.ranks_on_my_device(self.device)) // per_token
         return tpd.tp_all_gather_min_int(n, self.device)
 
     def initialize_kv_cache(self, kv_cache_size: int):

@@ -326,6 +326,18 @@ def all_ranks_min_int(value: int, device) -> int:
 tp_all_gather_min_int = all_ranks_min_int
 
 
+def ranks_on_my_device(device) -> int:
+    """How many ranks of the job run on this rank's GPU: 1 with one process per GPU (the product layout); more only when
+    several ranks are rehearsed on one device."""
+    if _TP_SIZE * _PP_SIZE == 1 or torch.device(device).type != "cuda":
+        return 1
+    mine = torch.device(device).index
+    mine = torch.cuda.current_device() if mine is None else mine
+    all_devices = [None] * dist.get_world_size()
+    dist.all_gather_object(all_devices, mine)
+    return max(1, sum(1 for d in all_devices if d == mine)) if dist.get_backend() == "gloo" else 1
+
+
 # -- pipeline stages: activations between neighbouring stages ---------------------------------------
 def _slice_for_peer(x: torch.Tensor) -> torch.Tensor:
     """This TP rank's 1/tp of the flattened tensor (communication_op.py:277-279); the whole tensor when
