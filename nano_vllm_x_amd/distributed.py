@@ -150,6 +150,12 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
         return _PEER is not None
     tp, rank = max(_TP_SIZE, 1), _TP_RANK
     group, err = None, None
+    if tp > 1 and ranks_on_my_device(device) > 1:
+        # Ranks rehearsed on ONE device: a peer's exchange kernel waits for this rank with a workgroup on every CU, so a
+        # kernel of this rank that needs a whole SIMD's registers (the 64-row gate/up projection, used from 112 rows)
+        # could never be placed and every wait would run into its time-out.  Keep that kernel off (the library reads the
+        # variable at its first projection, which comes later).  Ranks on GPUs of their own never share a CU.
+        os.environ.setdefault("NVX_LIN_GATEUP_WIDE_MIN", "1000000")
     # one routing limit for the whole group (a rank that read another NVX_PEER_MAX_PUSH_BYTES would send a tensor through
     # the library while its peers wait for it in the exchange kernel): the smallest any rank holds
     push = ops.PeerGroup.MAX_PUSH_BYTES
