@@ -88,11 +88,25 @@ DECODE_LINEAR_MAX_ROWS = {"qkv": 256, "o": 256, "gate_up": 256, "down": 256}
 DECODE_LINEAR_MAX_WEIGHT_BYTES = 16 << 20
 
 
+# NVX_FP32_LINEAR=1 (read when a model is built): every dense projection, the LM head included, multiplies in fp32 and
+# rounds its result to the model's 16-bit format once (the LM head's logits stay fp32).  Not a serving mode: it takes
+# the library GEMMs' and the skinny kernels' summation order out of a comparison, so that what differs from an fp32
+# restatement of the model is the hand-written path alone (norms, rotary, KV scatter, attention).
+FP32_LINEAR = False
+
+
+def linear_fp32(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return F.linear(x.float(), weight.float()).to(x.dtype)
+
+
 def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
     """Projection of a decode batch.  Returns bf16 (rows, n) -- or, for the row-parallel projections
     ("o", "down") on a single rank, fp32 partial products (splits, rows, n) that the RMSNorm which
     follows sums (under tensor parallelism they stay 16-bit: the sum over ranks comes first);
     "gate_up" returns SiluAndMul of the projection, (rows, n/2)."""
+    if FP32_LINEAR:
+        y = linear_fp32(x, weight)
+        return ops.silu_mul(y) if kind == "gate_up" else y
     rows, k = x.shape
     n = weight.shape[0]
     use = (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and rows <= DECODE_LINEAR_MAX_ROWS[kind] and x.stride(1) == 1
@@ -159,7 +173,7 @@ class Qwen3Attention(nn.Module):
                 attn_out = self.attn(q, None, None)
             out = decode_linear(attn_out, self.o_proj.weight, "o")
             return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
-        qkv = self.qkv_proj(hidden_states)
+        qkv = linear_fp32(hidden_states, self.qkv_proj.weight) if FP32_LINEAR else self.qkv_proj(hidden_states)
         if fused:
             k_cache, v_cache = md.kv_cache.get_kv_cache(self.attn.layer_id)
             q = ops.qknorm_rope_store(qkv, positions, self.rope_table, self.q_norm.weight, self.k_norm.weight, self.eps,
@@ -172,7 +186,7 @@ class Qwen3Attention(nn.Module):
             k = self.k_norm(k.reshape(t, self.num_kv_heads, self.head_dim)).view(t, self.kv_size)
             q, k = ops.rope(positions, q, k, self.rope_table)
             attn_out = self.attn(q, k, v.contiguous())
-        out = self.o_proj(attn_out)
+        out = linear_fp32(attn_out, self.o_proj.weight) if FP32_LINEAR else self.o_proj(attn_out)
         return tpd.tp_reduce_later(out)
 
 
@@ -188,6 +202,8 @@ class Qwen3MLP(nn.Module):
         if decode:
             out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up"), self.down_proj.weight, "down")
             return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
+        if FP32_LINEAR:
+            return tpd.tp_reduce_later(linear_fp32(self.act_fn(linear_fp32(x, self.gate_up_proj.weight)), self.down_proj.weight))
         return tpd.tp_reduce_later(self.down_proj(self.act_fn(self.gate_up_proj(x))))
 
 
@@ -344,6 +360,8 @@ class Qwen3ForCausalLM(nn.Module):
         self.model = Qwen3Model(cfg)
         self.lm_head = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size) if tpd.pp_is_last() else MissingLayer()
         self.fused = True
+        global FP32_LINEAR
+        FP32_LINEAR = os.environ.get("NVX_FP32_LINEAR") == "1"
 
     def finalize(self):
         """Call after .to(device, dtype): restore the fp32 rotary table and share it with every layer
@@ -361,6 +379,8 @@ class Qwen3ForCausalLM(nn.Module):
         return self.model(input_ids, positions, self.fused)
 
     def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        if FP32_LINEAR:
+            return tpd.tp_all_gather_last_dim(F.linear(hidden_states.float(), self.lm_head.weight.float()))[..., :self.config.vocab_size]
         logits = tpd.tp_all_gather_last_dim(F.linear(hidden_states, self.lm_head.weight))
         return logits[..., :self.config.vocab_size]
 

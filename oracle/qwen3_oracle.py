@@ -36,7 +36,13 @@ def pack_weights_oracle(sd: dict, n_layers: int):
     return out
 
 
-def qwen3_forward_oracle(w, cfg, input_ids, positions, k_cache, v_cache, table, rope_table):
+def _linear_oracle(x, weight, fp32: bool):
+    """linear.py:73,169,276: F.linear in the tensors' dtype -- or, `fp32`, the product in fp32 rounded once to the
+    activations' dtype (what a 16-bit GEMM with fp32 accumulation computes, minus its summation order)."""
+    return F.linear(x.float(), weight.float()).to(x.dtype) if fp32 else F.linear(x, weight)
+
+
+def qwen3_forward_oracle(w, cfg, input_ids, positions, k_cache, v_cache, table, rope_table, linear_fp32=False):
     """One forward over the flattened new tokens of a batch.
 
     k_cache/v_cache: (layers, slots, Hkv, D), updated in place.  `table`: block_table_oracle()."""
@@ -52,7 +58,7 @@ def qwen3_forward_oracle(w, cfg, input_ids, positions, k_cache, v_cache, table, 
             res, x = h, rmsnorm_oracle(h, lw["ln1"], eps)
         else:
             x, res = rmsnorm_oracle(h, lw["ln1"], eps, res)
-        qkv = F.linear(x, lw["qkv"])
+        qkv = _linear_oracle(x, lw["qkv"], linear_fp32)
         q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
         t = q.shape[0]
         q = rmsnorm_oracle(q.reshape(t, hq, d), lw["q_norm"], eps).reshape(t, hq * d)
@@ -63,9 +69,9 @@ def qwen3_forward_oracle(w, cfg, input_ids, positions, k_cache, v_cache, table, 
         v_cache[l][out_slots[live]] = v.reshape(t, hkv, d)[live]
         a = paged_attention_oracle(q.reshape(t, hq, d), k_cache[l], v_cache[l], table["qo_indptr"],
                                    table["kv_indptr"], table["kv_indices"], d ** -0.5)
-        h = F.linear(a.reshape(t, hq * d), lw["o"])
+        h = _linear_oracle(a.reshape(t, hq * d).to(x.dtype), lw["o"], linear_fp32)
         x, res = rmsnorm_oracle(h, lw["ln2"], eps, res)
-        h = F.linear(silu_mul_oracle(F.linear(x, lw["gate_up"])), lw["down"])
+        h = _linear_oracle(silu_mul_oracle(_linear_oracle(x, lw["gate_up"], linear_fp32)), lw["down"], linear_fp32)
     y, _ = rmsnorm_oracle(h, w["final_norm"], eps, res)
     return y
 
@@ -75,7 +81,9 @@ def last_rows_oracle(table):
     return (np.asarray(table["qo_indptr"][1:], dtype=np.int64) - 1).tolist()
 
 
-def logits_oracle(w, hidden_last):
+def logits_oracle(w, hidden_last, linear_fp32=False):
+    if linear_fp32:      # fp32 logits from the 16-bit hidden states
+        return F.linear(hidden_last.float(), w["lm_head"].float())
     return F.linear(hidden_last, w["lm_head"])
 
 
@@ -141,7 +149,7 @@ def cpu_engine_run_oracle(cfg, prompts, max_tokens, kv_slots, max_bs, context_le
 
 
 def cpu_engine_greedy_oracle(cfg, state_dict, prompts, max_new_tokens, kv_slots, max_bs, context_len, dtype=torch.float32,
-                             keep_logits=True, forced=None):
+                             keep_logits=True, forced=None, linear_fp32=False):
     """The serving loop on CPU with arg-max sampling (what temperature -> 0 or top_k = 1 gives): oracle
     scheduler + oracle model over the weights of `state_dict` (Hugging Face names, as checkpoints and
     nano_vllm_x_amd.qwen3.random_checkpoint give them), cast to `dtype`.
@@ -173,8 +181,8 @@ def cpu_engine_greedy_oracle(cfg, state_dict, prompts, max_new_tokens, kv_slots,
             table = block_table_oracle(rows)
             ids = [t for s in b.seqs for t in s.token_ids[s.cached_kv_len:]]
             pos = [p for s in b.seqs for p in range(s.cached_kv_len, len(s.token_ids))]
-            hid = qwen3_forward_oracle(w, cfg, ids, pos, k_cache, v_cache, table, rope)
-            lg = logits_oracle(w, hid[last_rows_oracle(table)]).float()
+            hid = qwen3_forward_oracle(w, cfg, ids, pos, k_cache, v_cache, table, rope, linear_fp32)
+            lg = logits_oracle(w, hid[last_rows_oracle(table)], linear_fp32).float()
             toks = lg.argmax(dim=-1).tolist()
             for j, s in enumerate(b.seqs):
                 i = int(s.seq_id)
