@@ -24,7 +24,7 @@ is within one unit in the last place or 1e-3 of its own oracle in test_gpu_float
 is those last-place differences carried through three layers of norms and a 512-term LM-head sum.
 
 What IS asserted, because it is what the tolerance is for (the device path must not be a worse float16 implementation
-than the reference's): hip is no further from exact arithmetic than ref16 is (max and rms, 10 % slack), hip and ref16
+than the reference's): hip is no further from exact arithmetic than ref16 is (rms with 10 % slack, max with 50 %), hip and ref16
 are no further apart than either is from exact arithmetic (same slack), the rms difference per logit is within
 1.5e-3, every arg-max agrees unless ref32's own top two are closer than the error, and the fraction of the 1e-3 bound
 that was reached is recorded (gpurun_out/model_tolerances_observed.json) so a change in it is seen.
@@ -99,9 +99,10 @@ def test_hand_written_path_alone_is_as_close_to_exact_arithmetic_as_eager_float1
     record(tag + "_ref16_vs_fp32_max_abs", fmt_max)
     print(f"isolated {hq}/{hkv}: hip vs ref16 max {d_max:.3e} rms {d_rms:.3e} ({d_frac:.2f} x the 1e-3 bound); "
           f"hip vs fp32 max {hip_max:.3e} rms {hip_rms:.3e}; ref16 vs fp32 max {fmt_max:.3e} rms {fmt_rms:.3e} ({fmt_frac:.2f} x)")
-    slack = 1.10
-    assert hip_max <= slack * fmt_max and hip_rms <= slack * fmt_rms, "the device path is further from exact arithmetic than eager float16 is"
-    assert d_max <= slack * max(fmt_max, hip_max) and d_rms <= slack * max(fmt_rms, hip_rms), \
+    # the rms over 61 440 logits is a stable statistic (10 % slack); the maximum is one sample of a 4.5-sigma tail (50 %)
+    slack, slack_max = 1.10, 1.50
+    assert hip_max <= slack_max * fmt_max and hip_rms <= slack * fmt_rms, "the device path is further from exact arithmetic than eager float16 is"
+    assert d_max <= slack_max * max(fmt_max, hip_max) and d_rms <= slack * max(fmt_rms, hip_rms), \
         "the device path and the float16 oracle are further apart than either is from exact arithmetic"
     assert d_rms <= 1.5e-3
     # arg-max: the same token unless exact arithmetic itself rates the two candidates closer than the float16 error
