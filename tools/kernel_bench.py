@@ -83,6 +83,7 @@ def cmd_decode(args):
     ws = ops.DecodeWorkspace(2048 if args.hkv1 else 256, HQ, HKV, DEV)
     tot_b = tot_t = 0.0
     rows_out = []
+    buckets = {}
     layer = [0]
     for i, (lens, flat) in enumerate(batches):
         b = len(lens)
@@ -129,13 +130,21 @@ def cmd_decode(args):
         alg = rows * 2 * HKV * 128 * 2 + 2 * b * HQ * 128 * 2 + 4 * rows
         tot_b += alg
         tot_t += t
+        bucket = next(hi for hi in (2, 4, 8, 16, 32, 64, 128, 256) if b <= hi)
+        acc = buckets.setdefault(bucket, [0, 0.0, 0.0])
+        acc[0] += 1; acc[1] += t; acc[2] += alg
         if i % max(1, len(batches) // 12) == 0:
             rows_out.append((i * args.every, b, rows, round(t * 1e6, 1), round(alg / t / 1e9), int(ws.plan[0]), int(ws.plan[1])))
     print("step  B  kv_rows  us  GB/s  items chunk")
     for r in rows_out:
         print(*r)
     print(json.dumps({"kernel": "paged_decode(+merge)", "heads": [HQ, HKV], "batches": len(batches), "avg_us": round(tot_t / len(batches) * 1e6, 2),
-                      "GBps": round(tot_b / tot_t / 1e9, 1), "frac_of_8TBps": round(tot_b / tot_t / 8e12, 4)}))
+                      "GBps": round(tot_b / tot_t / 1e9, 1), "frac_of_8TBps": round(tot_b / tot_t / 8e12, 4),
+                      "variant": "qkv" if args.qkv else "unfused" if args.unfused else "plain",
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("NVX_DEC")},
+                      # by decode batch size (sequences per step, upper edge of the bucket): launches sampled, mean us per launch pair, GB/s
+                      "by_batch": {f"<={hi}": {"batches": n, "avg_us": round(tt / n * 1e6, 2), "GBps": round(bb / tt / 1e9, 1),
+                                               "frac_of_8TBps": round(bb / tt / 8e12, 4)} for hi, (n, tt, bb) in sorted(buckets.items())}}))
 
 
 def cmd_prefill(args):
