@@ -31,6 +31,18 @@ namespace NVX_NS {
 #define DEC_PART_STRIDE 132     // floats per (item, q head): 128 acc + m + l (+2 pad)
 #define DEC_REC_INTS 8          // per item: seq, n_tokens, n_chunks_of_seq, chunk_index, abs_lo, abs_hi, 0, new_slot
 #define DEC_LOG2E 1.4426950408889634f
+#ifndef DEC_TQ_G2
+#define DEC_TQ_G2 2
+#endif
+#ifndef DEC_G4_MIN_WGS
+#define DEC_G4_MIN_WGS 2        // workgroups per CU the compiler must leave room for at three or four query heads per kv head
+#endif
+#ifndef DEC_TQ_G4
+#define DEC_TQ_G4 2
+#endif
+#ifndef DEC_SHARE_Q_MIN_G
+#define DEC_SHARE_Q_MIN_G 2     // smallest query group whose heads are prepared once per workgroup (QKV variant, register kernel)
+#endif
 
 static inline int64_t dec_max_items(int64_t max_batch, int n_kv_heads) {
     return max_batch + 2048 / (n_kv_heads > 0 ? n_kv_heads : 1) + 8;
@@ -254,14 +266,18 @@ __device__ __forceinline__ nvx_u32x4 dec_new_key(const uint16_t* row, int hq_tot
 //   the new key, writes the new k/v row into the pool and attends to it from registers (the row is the
 //   last entry of the sequence's slot list and is skipped when reading the pool).
 template <int G, int TPQ, bool QKV>
-__global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) ? 4 : 2)) void paged_decode_kernel(
+__global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) ? 4 : (G <= 4 ? DEC_G4_MIN_WGS : 2))) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, int64_t n_slots, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ plan, float* __restrict__ partial, uint16_t* __restrict__ out, int hkv,
     float scale_log2, DecQkv fx) {
     constexpr int TILE = 4 * TPQ;
     constexpr int STEP = 4 * TILE;   // four waves interleave their tiles
+    // QKV variant, wide groups: the G query heads are normalised and rotated ONCE per workgroup (quarter-wave i of the
+    // sixteen takes head i) and handed round through LDS, instead of by every quarter-wave for itself
+    constexpr bool SHARE_Q = QKV && G >= DEC_SHARE_Q_MIN_G;
     __shared__ float lds[4][G][16][10];  // [wave][head in group][piece] -> m, l, acc[8]
+    __shared__ nvx_u32x4 q_shared[SHARE_Q ? G : 1][16];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int quarter = lane >> 4, piece = lane & 15;
@@ -298,13 +314,18 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
         dec_load_slots<TPQ>(slots, idx_base, tile, quarter, n_pool);
 
         nvx_u32x4 qv[G];
-        HalfQuad qraw[QKV ? G : 1];
+        HalfQuad qraw[(QKV && !SHARE_Q) ? G : 1];
         const uint16_t* qrow = q + (int64_t)b * q_stride;
         const float* cs = nullptr;
+        const int qid = wave * 4 + quarter;   // this quarter-wave among the workgroup's sixteen
         if (QKV) {
             cs = fx.cos_sin + clamp_pos(fx.positions[b], fx.max_pos) * 128;
+            if (SHARE_Q) {
+                if (qid < G) qraw[0] = load_half_quads(qrow + (head * G + qid) * 128, piece);
+            } else {
 #pragma unroll
-            for (int g = 0; g < G; ++g) qraw[g] = load_half_quads(qrow + (head * G + g) * 128, piece);
+                for (int g = 0; g < G; ++g) qraw[g] = load_half_quads(qrow + (head * G + g) * 128, piece);
+            }
         } else {
 #pragma unroll
             for (int g = 0; g < G; ++g) qv[g] = *reinterpret_cast<const nvx_u32x4*>(qrow + (head * G + g) * 128 + piece * 8);
@@ -328,10 +349,20 @@ __global__ __launch_bounds__(256, ((G <= 2 && (TPQ <= 2 || (TPQ <= 4 && !QKV))) 
                 dec_issue<TPQ>(ta, slots, kb, vb, row_bytes, n_slots_u);
                 dec_load_slots<TPQ>(slots, idx_base, tile + STEP, quarter, n_pool);
             }
+            if (SHARE_Q) {
+                if (qid < G) {
+                    const uint4 o = norm_rotate_interleave(qraw[0], half_quad_sumsq(qraw[0]), fx.q_weight, fx.eps, cs, piece);
+                    q_shared[qid][piece] = nvx_u32x4{o.x, o.y, o.z, o.w};
+                }
+                __syncthreads();   // (the two barriers at the end of a unit keep the next unit's writes behind these reads)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint4 o = norm_rotate_interleave(qraw[g], half_quad_sumsq(qraw[g]), fx.q_weight, fx.eps, cs, piece);
-                qv[g] = nvx_u32x4{o.x, o.y, o.z, o.w};
+                for (int g = 0; g < G; ++g) qv[g] = q_shared[g][piece];
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint4 o = norm_rotate_interleave(qraw[g], half_quad_sumsq(qraw[g]), fx.q_weight, fx.eps, cs, piece);
+                    qv[g] = nvx_u32x4{o.x, o.y, o.z, o.w};
+                }
             }
             if (any) {
                 dec_compute<G, TPQ>(ta, qv, m, l, acc, scale_log2);
@@ -869,8 +900,8 @@ static int dec_launch(const void* q, int64_t q_row_stride, const void* k_cache, 
     } else
     switch (g) {
         case 1: NVX_DEC(1, 4, 4); break;
-        case 2: NVX_DEC(2, 4, 2); break;   // plain: 112 VGPRs, four workgroups per CU; measured best of TPQ 2/4/8/16
-        case 4: NVX_DEC(4, 4, 2); break;
+        case 2: NVX_DEC(2, 4, DEC_TQ_G2); break;   // plain: 112 VGPRs, four workgroups per CU; measured best of TPQ 2/4/8/16
+        case 4: NVX_DEC(4, 4, DEC_TQ_G4); break;
         case 8: NVX_DEC(8, 2, 2); break;
         default: return nvx_fail(NVX_EUNSUPPORTED, "%s: query/kv head ratio %d not in {1,2,4,8}", who, g);
     }
