@@ -183,9 +183,9 @@ def decode_attention_roofline(runner, batches, reps: int = 14):
         launches += reps
     achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            # the counter passes were taken on the default geometry (16 query / 8 kv heads per rank): no figure for another
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic("paged_decode_kernel") if (runner.num_heads, runner.num_kv_heads) == (16, 8) else None,
+            # the counter passes exist for two geometries: 16 / 8 heads per rank (the headline) and 32 / 8 (Qwen3-8B on one GPU)
+            "traffic": _pmc_traffic("paged_decode_kernel", runner.num_heads, runner.num_kv_heads),
             "kernel": f"nvx_paged_decode_qkv ({runner.num_heads} query / {runner.num_kv_heads} kv heads"
                       + (": paged_decode_kernel<2,2,true>" if (runner.num_heads, runner.num_kv_heads) == (16, 8) else "")
                       + ") + decode_merge_kernel", "launches": launches,
@@ -264,7 +264,7 @@ def _pmc_prefill_traffic():
     import hashlib
 
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_prefill.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_prefill.json")) as f:
             d = json.load(f)
         stamp = d["kernel_source"]
         with open(os.path.join(ROOT, stamp["file"]), "rb") as f:
@@ -275,19 +275,19 @@ def _pmc_prefill_traffic():
         return None
 
 
-def _pmc_traffic(kernel: str):
+def _pmc_traffic(kernel: str, hq: int = 16, hkv: int = 8):
     """HBM bytes per launch from rocprofv3 PMC passes, if a summary has been committed AND was taken from the
     kernel source this run uses (the summary records the source file's SHA-256); a summary of another revision
     is reported as None rather than passed off as this kernel's traffic."""
     import hashlib
 
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if (hq, hkv) == (16, 8) else f"pmc_traffic_{hq}_{hkv}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         d = json.load(f)
     stamp = d.get("kernel_source")
-    if not stamp or kernel not in d:
+    if not stamp or kernel not in d or list(d.get("heads (query, kv)", [16, 8])) != [hq, hkv]:
         return None
     try:
         with open(os.path.join(ROOT, stamp["file"]), "rb") as f:

@@ -23,7 +23,9 @@ from nano_vllm_x_amd import ops
 DEV = "cuda:0"
 HQ, HKV, LAYERS = 16, 8, 28
 EVERY = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-OUT = sys.argv[2] if len(sys.argv) > 2 else None
+OUT = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+if len(sys.argv) > 3:      # query,kv head counts of another geometry, e.g. 32,8 (Qwen3-8B on one GPU)
+    HQ, HKV = (int(x) for x in sys.argv[3].split(","))
 
 
 def main():
@@ -59,7 +61,7 @@ def main():
         rows = int(lens.sum())
         alg.append(rows * 2 * HKV * 128 * 2 + b * (HQ + 2 * HKV) * 128 * 2 + b * HQ * 128 * 2 + 4 * rows)
     torch.cuda.synchronize()
-    info = {"launches": len(alg), "avg_algorithmic_bytes": sum(alg) / len(alg), "calibration_bytes_each_way": cal.numel() * 4}
+    info = {"heads": [HQ, HKV], "launches": len(alg), "avg_algorithmic_bytes": sum(alg) / len(alg), "calibration_bytes_each_way": cal.numel() * 4}
     print(json.dumps(info))
     if OUT:
         with open(OUT, "w") as f:

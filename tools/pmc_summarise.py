@@ -64,7 +64,7 @@ def per_kernel(path, counter):
 def main():
     info = json.load(open(sys.argv[1]))
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_decode.py",
-           "unit": "bytes per launch", "launches": info["launches"], "avg_algorithmic_bytes": info["avg_algorithmic_bytes"],
+           "unit": "bytes per launch", "heads (query, kv)": info.get("heads", [16, 8]), "launches": info["launches"], "avg_algorithmic_bytes": info["avg_algorithmic_bytes"],
            "kernel_source": source_stamp("nano_vllm_x_amd/csrc/decode_attn.hip")}
     fetch = per_kernel(sys.argv[2], "FETCH_SIZE")
     for k, (n, kib) in fetch.items():
