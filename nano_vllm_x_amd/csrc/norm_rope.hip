@@ -4,6 +4,8 @@
 #include "nvx_dev.h"
 #include "rope_dev.h"
 
+#define NVX_RMSNORM_ROW_KERNEL_MAX_ROWS 1024
+
 namespace NVX_NS {
 
 // ---------------------------------------------------------------------------------------------
@@ -76,6 +78,100 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
     }
 }
 
+// The same norm for FEW, WIDE rows (a decode batch at hidden sizes of 2048 and more): one 256-thread workgroup per row,
+// thread t owns elements 8t .. 8t+7 of every 2048-wide slab, every load of the row (x, residual, weight) is issued before
+// the first use, the sum of squares crosses the waves through LDS.  With one WAVE per row (above) a 4096-wide row is eight
+// dependent round trips on a handful of CUs: 9.5 us at 29 rows where this takes a third of that.  Per-element arithmetic
+// is the kernel's above; only the order in which the squares are summed differs.
+template <int SLABS, bool HAS_RES, bool W_F32>
+__global__ __launch_bounds__(256) void rmsnorm_row_kernel(
+    const uint16_t* __restrict__ x, int64_t x_stride, const uint16_t* residual, const void* __restrict__ weight,
+    uint16_t* y, uint16_t* residual_out, int hidden, float eps) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const uint16_t* xr = x + row * x_stride;
+    uint4 a[SLABS], r[SLABS], wv[SLABS];
+    float4 wf[SLABS][2];
+#pragma unroll
+    for (int it = 0; it < SLABS; ++it) {
+        const int col = it * 2048 + tid * 8;
+        if (col < hidden) {
+            a[it] = *reinterpret_cast<const uint4*>(xr + col);
+            if (HAS_RES) r[it] = *reinterpret_cast<const uint4*>(residual + row * hidden + col);
+            if (W_F32) {
+                wf[it][0] = *reinterpret_cast<const float4*>((const float*)weight + col);
+                wf[it][1] = *reinterpret_cast<const float4*>((const float*)weight + col + 4);
+            } else {
+                wv[it] = *reinterpret_cast<const uint4*>((const uint16_t*)weight + col);
+            }
+        }
+    }
+    float v[SLABS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < SLABS; ++it) {
+        const int col = it * 2048 + tid * 8;
+        if (col < hidden) {
+            const uint32_t aw[4] = {a[it].x, a[it].y, a[it].z, a[it].w};
+            if (HAS_RES) {
+                const uint32_t rw[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = h16lo_to_f32(aw[j]) + h16lo_to_f32(rw[j]);
+                    const float hi = h16hi_to_f32(aw[j]) + h16hi_to_f32(rw[j]);
+                    v[it][2 * j] = lo;
+                    v[it][2 * j + 1] = hi;
+                    ow[j] = pack_h16x2(lo, hi);
+                }
+                *reinterpret_cast<uint4*>(residual_out + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[it][2 * j] = h16lo_to_f32(aw[j]); v[it][2 * j + 1] = h16hi_to_f32(aw[j]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int it = 0; it < SLABS; ++it) {
+        const int col = it * 2048 + tid * 8;
+        if (col < hidden) {
+            float w[8];
+            if (W_F32) {
+                w[0] = wf[it][0].x; w[1] = wf[it][0].y; w[2] = wf[it][0].z; w[3] = wf[it][0].w;
+                w[4] = wf[it][1].x; w[5] = wf[it][1].y; w[6] = wf[it][1].z; w[7] = wf[it][1].w;
+            } else {
+                const uint32_t ww[4] = {wv[it].x, wv[it].y, wv[it].z, wv[it].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { w[2 * j] = h16lo_to_f32(ww[j]); w[2 * j + 1] = h16hi_to_f32(ww[j]); }
+            }
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ow[j] = pack_h16x2((v[it][2 * j] * inv) * w[2 * j], (v[it][2 * j + 1] * inv) * w[2 * j + 1]);
+            *reinterpret_cast<uint4*>(y + row * hidden + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+template <int SLABS>
+static void launch_rmsnorm_rows(const void* x, int64_t xs, const void* res, const void* w, int wf32, void* y, void* ro,
+                                int64_t rows, int hidden, float eps, hipStream_t st) {
+    const dim3 grid((unsigned)rows), block(256);
+#define NVX_RMSR(HR, WF) hipLaunchKernelGGL((rmsnorm_row_kernel<SLABS, HR, WF>), grid, block, 0, st, (const uint16_t*)x, xs, \
+        (const uint16_t*)res, w, (uint16_t*)y, (uint16_t*)ro, hidden, eps)
+    if (res) { if (wf32) NVX_RMSR(true, true); else NVX_RMSR(true, false); }
+    else     { if (wf32) NVX_RMSR(false, true); else NVX_RMSR(false, false); }
+#undef NVX_RMSR
+}
+
 template <int ITERS>
 static void launch_rmsnorm(const void* x, int64_t xs, const void* res, const void* w, int wf32, void* y, void* ro,
                            int64_t rows, int hidden, float eps, hipStream_t st) {
@@ -101,6 +197,14 @@ extern "C" int NVX_ENTRY(nvx_rmsnorm)(const void* x, int64_t x_row_stride, const
                 NVX_EINVAL, "nvx_rmsnorm: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int h = (int)hidden;
+    // few wide rows (decode batches of the larger models): a workgroup per row
+    if (h > 1024 && rows <= NVX_RMSNORM_ROW_KERNEL_MAX_ROWS) {
+        if (h <= 2048) launch_rmsnorm_rows<1>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+        else if (h <= 4096) launch_rmsnorm_rows<2>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+        else if (h <= 6144) launch_rmsnorm_rows<3>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+        else launch_rmsnorm_rows<4>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
+        return nvx_check_launch("nvx_rmsnorm");
+    }
     if (h <= 512) launch_rmsnorm<1>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
     else if (h <= 1024) launch_rmsnorm<2>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
     else if (h <= 2048) launch_rmsnorm<4>(x, x_row_stride, residual, weight, weight_is_f32, y, residual_out, rows, h, eps, st);
@@ -330,12 +434,15 @@ extern "C" int NVX_ENTRY(nvx_qknorm_rope_store)(const void* qkv, int64_t qkv_row
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_h16(float x) { return round_h16(x / (1.0f + __expf(-x))); }
 
+// IDX: the type the element index is counted in.  A 64-bit division per element costs about a hundred instructions;
+// every decode batch and most prefill batches fit 32 bits.
+template <typename IDX>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        int64_t rows, int d8) {
-    const int64_t total = rows * d8;
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-        const int64_t r = id / d8;
-        const int c = (int)(id % d8);
+    const IDX total = (IDX)(rows * d8);
+    for (IDX id = (IDX)blockIdx.x * 256 + threadIdx.x; id < total; id += (IDX)gridDim.x * 256) {
+        const int64_t r = (int64_t)(id / (IDX)d8);
+        const int c = (int)(id % (IDX)d8);
         const uint4 g = *reinterpret_cast<const uint4*>(x + (r * 2 * d8 + c) * 8);
         const uint4 u = *reinterpret_cast<const uint4*>(x + (r * 2 * d8 + d8 + c) * 8);
         const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
@@ -357,8 +464,12 @@ extern "C" int NVX_ENTRY(nvx_silu_mul)(const void* x, void* y, int64_t rows, int
     const int64_t total = rows * (d / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)x, (uint16_t*)y, rows, (int)(d / 8));
+    if (total + 256 * 256 * 16 < 0x7fffffffll)
+        hipLaunchKernelGGL(silu_mul_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (uint16_t*)y, rows, (int)(d / 8));
+    else
+        hipLaunchKernelGGL(silu_mul_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (uint16_t*)y, rows, (int)(d / 8));
     return nvx_check_launch("nvx_silu_mul");
 }
 

@@ -126,6 +126,17 @@ def test_rmsnorm_vs_oracle_sizes(ops, hidden):
     big[:, :hidden] = x
     y3 = ops.rmsnorm(big.to(DEV)[:, :hidden], w.float().to(DEV), 1e-6)
     assert bf16_ulp_diff(y3, rmsnorm_oracle(x, w.float(), 1e-6)) <= 1
+    # few wide rows take a workgroup per row, many rows a wave per row: the second kernel on the same widths
+    if hidden > 1024:
+        many = 1100
+        xm = (torch.randn(many, hidden, generator=gen) * 2).to(torch.bfloat16)
+        rm = torch.randn(many, hidden, generator=gen).to(torch.bfloat16)
+        ym_ref, rm_ref = rmsnorm_oracle(xm, w, 1e-6, rm)
+        ym, rom = ops.rmsnorm(xm.to(DEV), w.to(DEV), 1e-6, rm.to(DEV))
+        assert bf16_ulp_diff(ym, ym_ref) <= 1 and np.array_equal(to_bits(rom), to_bits(rm_ref))
+        # ... and both kernels give the same rows where both apply
+        few, _ = ops.rmsnorm(xm[:37].to(DEV), w.to(DEV), 1e-6, rm[:37].to(DEV))
+        assert bf16_ulp_diff(few, ym[:37]) <= 1
 
 
 def test_rope_golden_bit_exact(ops):
