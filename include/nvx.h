@@ -41,7 +41,7 @@ typedef void* nvx_stream_t;
  *   2: nvx_decode_step_setup gained `prev_ids`.
  *   3: float16 entry points (`*_f16`) added.
  *   4: direct-peer all-reduce (`nvx_peer_*`) and sharded sampling (`nvx_sample_shard`, `nvx_sample_pick`) added. */
-#define NVX_ABI_VERSION 4
+#define NVX_ABI_VERSION 5
 
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
@@ -279,6 +279,34 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
                           nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * LM head of a decode step that draws as it computes: logits = x (batch, k) . W^T (n_rows, k), then one token per
+ * row, in ONE pass over W.  Replaces, for rows without top-k / top-p / min-p, ParallelLMHead.forward followed by
+ * Sampler.forward (nanovllmx/layers/vocab_parallel_embedding.py:147-151, core/model_runner.py:262-272,
+ * layers/sampler.py:39-55): the logits never travel to memory and back.
+ *
+ * nvx_lmhead_pack repacks W (n_rows, k) 16-bit row-major, once at load time, into tiles of 16 rows whose 16-byte
+ * pieces are in matrix-core operand order (nvx_lmhead_packed_elems() elements; rows past n_rows are zeros), so that
+ * the kernel's loads are whole 1 KB lines that go straight into operand registers.
+ *
+ * nvx_lmhead_sample: x rows x_row_stride elements apart, batch <= nvx_lmhead_max_rows() (the batch stays in the LDS
+ * of every compute unit), k = 1024.  Row r of W is token vocab_offset + r of a vocabulary of `vocab` tokens (a
+ * tensor-parallel rank passes its shard; tokens >= vocab are padding and never drawn).  Every logit is rounded to the
+ * 16-bit format, as the projection would have stored it; the draw is nvx_sample's (same noise per (seed, offset,
+ * row, token), same tie rule; temperature <= 0: arg-max), so key_out / out_ids equal what nvx_sample_shard /
+ * nvx_sample give on those logits.  key_out (batch) receives the 64-bit (score, token) keys (for nvx_sample_pick
+ * over the ranks' keys), out_ids (batch) the token ids; either may be NULL.  logits_out (batch rows of
+ * logits_row_stride >= n_rows padded to 16 elements), if not NULL, receives the rounded logits.
+ * ws: >= nvx_lmhead_ws_bytes(batch) bytes, 8-byte aligned.  No allocation, no host sync, capturable. */
+int64_t nvx_lmhead_max_rows(void);
+int64_t nvx_lmhead_packed_elems(int64_t n_rows, int64_t k);
+int64_t nvx_lmhead_ws_bytes(int64_t batch);
+int nvx_lmhead_pack(const void* w, int64_t n_rows, int64_t k, void* packed, nvx_stream_t stream);
+int nvx_lmhead_sample(const void* w_packed, int64_t n_rows, int64_t k, const void* x, int64_t x_row_stride,
+                      int64_t batch, const float* temperatures, int64_t vocab_offset, int64_t vocab,
+                      uint64_t seed, uint64_t offset, void* ws, int64_t ws_bytes, uint64_t* key_out,
+                      int64_t* out_ids, void* logits_out, int64_t logits_row_stride, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Tensor-parallel all-reduce of a decode step, over memory the peers have mapped, fused with the
  * RMSNorm that follows it.  Replaces the NCCL all-reduce behind the row-parallel linears and the
  * vocab-parallel embedding (nanovllmx/distributed/communication_op.py:41-52,153-156, called from
@@ -371,6 +399,10 @@ int nvx_paged_prefill_f16(const void* q, int64_t q_row_stride, const void* k_cac
 int nvx_peer_allreduce_norm_f16(void* comm, const void* x, int64_t x_row_stride, const void* residual,
                             const void* weight, void* y, void* residual_out, int64_t rows,
                             int64_t hidden, float eps, nvx_stream_t stream);
+int nvx_lmhead_sample_f16(const void* w_packed, int64_t n_rows, int64_t k, const void* x, int64_t x_row_stride,
+                          int64_t batch, const float* temperatures, int64_t vocab_offset, int64_t vocab,
+                          uint64_t seed, uint64_t offset, void* ws, int64_t ws_bytes, uint64_t* key_out,
+                          int64_t* out_ids, void* logits_out, int64_t logits_row_stride, nvx_stream_t stream);
 
 #ifdef __cplusplus
 }

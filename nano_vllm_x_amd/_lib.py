@@ -67,6 +67,12 @@ SIGNATURES = {
     "nvx_peer_import": (_c_i32, [_c_vp, _c_i32, ctypes.c_char_p]),
     "nvx_peer_status": (_c_i32, [_c_vp]),
     "nvx_peer_destroy": (_c_i32, [_c_vp]),
+    "nvx_lmhead_max_rows": (_c_i64, []),
+    "nvx_lmhead_packed_elems": (_c_i64, [_c_i64, _c_i64]),
+    "nvx_lmhead_ws_bytes": (_c_i64, [_c_i64]),
+    "nvx_lmhead_pack": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
+    "nvx_lmhead_sample": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_u64, _c_u64, _c_vp, _c_i64, _c_vp,
+                                   _c_vp, _c_vp, _c_i64, _c_vp]),
     "nvx_peer_allreduce_norm": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_f32, _c_vp]),
 }
 
@@ -79,7 +85,7 @@ class NvxLibraryError(RuntimeError):
 
 # entry points that also exist as `<name>_f16` (IEEE half build of the same source, same signature)
 F16_ENTRY_POINTS = ("nvx_rmsnorm", "nvx_rope", "nvx_qknorm_rope_store", "nvx_silu_mul", "nvx_linear_decode", "nvx_rmsnorm_splitk",
-                    "nvx_paged_decode", "nvx_paged_decode_qkv", "nvx_paged_prefill", "nvx_peer_allreduce_norm")
+                    "nvx_paged_decode", "nvx_paged_decode_qkv", "nvx_paged_prefill", "nvx_peer_allreduce_norm", "nvx_lmhead_sample")
 for _name in F16_ENTRY_POINTS:
     SIGNATURES[_name + "_f16"] = SIGNATURES[_name]
 

@@ -98,6 +98,16 @@ class ModelRunner:
             else:
                 self.model.init_random(self.seed)
         self.sampler = Sampler(seed=self.seed)
+        # Decode-sized steps whose rows have no sampling filter take the LM head and the draw in ONE pass over the weight
+        # (ops.lmhead_sample): the tiled copy of this rank's LM-head rows it streams is made here, once.  NVX_LMHEAD_FUSED=0
+        # keeps the two-launch path (library projection + sampler) everywhere.
+        self._lmhead_packed = None
+        if (os.environ.get("NVX_LMHEAD_FUSED", "1") != "0" and tpd.pp_is_last() and cfg.hidden_size == 1024
+                and self.dtype in (torch.bfloat16, torch.float16)):
+            w = self.model.lm_head.weight
+            self._lmhead_packed = ops.lmhead_pack(w.detach())
+            self._lmhead_rows = w.shape[0]
+            self._lmhead_ws = ops.lmhead_workspace(ops.lmhead_max_rows(), self.device)
         # tensor-parallel ranks: all-reduces of decode-sized tensors go peer to peer (set up and proven here, before
         # the decode graph is captured; every rank falls back to the library all-reduce together if it cannot be)
         tpd.init_peer_allreduce(self.max_bs, cfg.hidden_size, self.dtype, self.device)
@@ -193,6 +203,15 @@ class ModelRunner:
         (None on a pipeline stage other than the last: its output went to the next stage).
         `ids_on_device`: the input ids are ids the step before sampled (see launch_step).
         `shard`: return (this rank's columns of the logits, id of their first token) instead of gathering the ranks'."""
+        hidden = self.compute_hidden(batch, ids_on_device)
+        if hidden is None:
+            return None
+        return self.model.compute_logits_shard(hidden) if shard else self.model.compute_logits(hidden)
+
+    @torch.inference_mode()
+    def compute_hidden(self, batch: ForwardBatch, ids_on_device=None):
+        """Forward pass of one scheduled batch -> the normed hidden state of each sequence's last token (num_seqs, hidden);
+        None on a pipeline stage other than the last."""
         decode = batch.forward_mode == ForwardMode.DECODE
         tpd.check_peer_status()      # results leave through here too (tests, tools): never on top of a failed exchange
         if self.graph_step_possible(batch):
@@ -207,8 +226,7 @@ class ModelRunner:
         self.stats["decode_steps" if decode else "prefill_steps"] += 1
         if hidden is None:
             return None
-        hidden = self.prepare_last_hidden_states(batch, hidden)
-        return self.model.compute_logits_shard(hidden) if shard else self.model.compute_logits(hidden)
+        return self.prepare_last_hidden_states(batch, hidden)
 
     @torch.inference_mode()
     def execute_model(self, batch: ForwardBatch) -> list:
@@ -229,6 +247,23 @@ class ModelRunner:
         t0 = time.perf_counter()
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
+        if (self._lmhead_packed is not None and self.pp_size == 1 and self._sp_unfiltered and n <= min(self.max_bs, ops.lmhead_max_rows())
+                and (self.tp_size == 1 or self.shard_sampling)):
+            # LM head and draw in one pass over this rank's rows of the weight; tensor-parallel ranks exchange one 64-bit key
+            # per row, as in the sharded path below
+            hidden = self.compute_hidden(batch, ids_on_device)
+            hidden = hidden if hidden.stride(-1) == 1 else hidden.contiguous()
+            self.sampler.calls += 1
+            start, vocab = self.model.lm_head.start, self.hf_config.vocab_size
+            if self.tp_size > 1:
+                keys = ops.lmhead_sample(self._lmhead_packed, self._lmhead_rows, hidden, temperatures, start, vocab, self.sampler.seed,
+                                         self.sampler.calls, ws=self._lmhead_ws, keys=True)
+                ids = ops.sample_pick(tpd.tp_all_gather_rows(keys), out=self._sample_out[:n])
+            else:
+                ids = ops.lmhead_sample(self._lmhead_packed, self._lmhead_rows, hidden, temperatures, start, vocab, self.sampler.seed,
+                                        self.sampler.calls, ws=self._lmhead_ws, out=self._sample_out[:n])
+            self.stats["fused_lm_head_steps"] = self.stats.get("fused_lm_head_steps", 0) + 1
+            return (batch, self._ids_to_host(ids, n), t0)
         if self.tp_size > 1 and self.pp_size == 1 and self._sp_unfiltered and n <= self.max_bs and self.shard_sampling:
             # every rank draws over its own shard of the vocabulary; the ranks exchange one 64-bit key per row and all
             # pick the same token: no gather of the logits (vocab_parallel_embedding.py:147-151), no broadcast of the ids

@@ -409,6 +409,53 @@ def sample_shard(logits, temperatures, vocab_offset: int, vocab: int, seed: int,
     return out
 
 
+def lmhead_max_rows() -> int:
+    return int(_lib.load().nvx_lmhead_max_rows())
+
+
+def lmhead_pack(weight):
+    """LM-head weight (rows, k) 16-bit -> the tiled copy lmhead_sample streams (built once, when the model is loaded)."""
+    _dev(weight)
+    _need(weight.dim() == 2 and weight.is_contiguous() and weight.dtype in H16 and weight.shape[1] % 32 == 0, "lmhead_pack: weight layout")
+    lib = _lib.load()
+    n, k = weight.shape
+    packed = torch.empty(int(lib.nvx_lmhead_packed_elems(n, k)), dtype=weight.dtype, device=weight.device)
+    _lib.check(lib.nvx_lmhead_pack(_ptr(weight), n, k, _ptr(packed), _stream()), "nvx_lmhead_pack")
+    return packed
+
+
+def lmhead_workspace(batch: int, device):
+    return torch.empty(int(_lib.load().nvx_lmhead_ws_bytes(batch)) // 8, dtype=torch.int64, device=device)
+
+
+def lmhead_sample(packed, n_rows: int, x, temperatures, vocab_offset: int, vocab: int, seed: int, offset: int, ws=None, keys=False,
+                  out=None, logits_out=None):
+    """hidden states x (B, k) -> one token per row (or, `keys`, the 64-bit (score, token) keys as int64 bit patterns, for
+    sample_pick over tensor-parallel ranks): the LM head and the unfiltered Gumbel-max draw in one pass over the packed
+    weight.  `logits_out` (B, >= n_rows padded to 16) receives the 16-bit logits if given."""
+    _dev(packed, x, temperatures, logits_out)
+    _need(x.dim() == 2 and x.stride(1) == 1 and x.dtype in H16 and packed.dtype == x.dtype, "lmhead_sample: x layout")
+    b, k = x.shape
+    _need(0 < b <= lmhead_max_rows(), "lmhead_sample: batch exceeds what the kernel keeps on a compute unit")
+    _need(temperatures.dtype == torch.float32 and temperatures.numel() == b and temperatures.is_contiguous(), "lmhead_sample: temperatures")
+    _need(packed.is_contiguous() and packed.numel() == ((n_rows + 15) // 16) * 16 * k, "lmhead_sample: packed weight size")
+    if ws is None:
+        ws = lmhead_workspace(b, x.device)
+    if out is None:
+        out = torch.empty((b,), dtype=torch.int64, device=x.device)
+    else:
+        _need(out.dtype == torch.int64 and out.numel() >= b and out.is_contiguous(), "lmhead_sample: out")
+    if logits_out is not None:
+        _need(logits_out.dim() == 2 and logits_out.dtype == x.dtype and logits_out.shape[0] >= b and logits_out.stride(1) == 1 and
+              logits_out.shape[1] >= ((n_rows + 15) // 16) * 16, "lmhead_sample: logits_out")
+    lib = _lib.load()
+    _lib.check(_fn(lib, "nvx_lmhead_sample", x.dtype)(_ptr(packed), n_rows, k, _ptr(x), x.stride(0), b, _ptr(temperatures), vocab_offset, vocab,
+                                                     seed & (2**64 - 1), offset & (2**64 - 1), _ptr(ws), ws.numel() * 8,
+                                                     _ptr(out) if keys else None, None if keys else _ptr(out), _ptr(logits_out),
+                                                     logits_out.stride(0) if logits_out is not None else 0, _stream()), "nvx_lmhead_sample")
+    return out
+
+
 def sample_pick(winners, out=None):
     """Token ids from the ranks' keys: winners (n_sets, B) int64 (bit patterns of the 64-bit keys) -> (B,) int64."""
     _dev(winners)

@@ -25,6 +25,9 @@ _DEFS = {
     "sampler_probs": "(Tensor logits, Tensor temperatures, Tensor top_ks, Tensor top_ps, Tensor min_ps) -> Tensor",
     "sample_shard": "(Tensor logits, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset) -> Tensor",
     "sample_pick": "(Tensor winners) -> Tensor",
+    "lmhead_pack": "(Tensor weight) -> Tensor",
+    "lmhead_sample": "(Tensor packed, int n_rows, Tensor x, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset, "
+                     "bool keys) -> Tensor",
     "qknorm_rope_store": "(Tensor qkv, Tensor positions, Tensor cos_sin, Tensor q_weight, Tensor k_weight, float eps, Tensor slots, "
                          "Tensor(a!) k_cache, Tensor(b!) v_cache, int n_q_heads, int n_kv_heads) -> Tensor",
     # paged attention, decode: plan once per step, then one call per layer
@@ -94,6 +97,14 @@ def _sample_shard(logits, temperatures, vocab_offset, vocab, seed, offset):
 
 def _sample_pick(winners):
     return ops.sample_pick(winners)
+
+
+def _lmhead_pack(weight):
+    return ops.lmhead_pack(weight)
+
+
+def _lmhead_sample(packed, n_rows, x, temperatures, vocab_offset, vocab, seed, offset, keys):
+    return ops.lmhead_sample(packed, n_rows, x, temperatures, vocab_offset, vocab, seed, offset, keys=keys)
 
 
 def _qknorm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, slots, k_cache, v_cache, n_q_heads, n_kv_heads):

@@ -231,6 +231,40 @@ def cmd_sampler(args):
         print(json.dumps(res))
 
 
+def cmd_lmhead(args):
+    """LM head + draw of a decode step (Qwen3-0.6B: 151 936 x 1024): the one-pass kernel against F.linear + the sampler.
+    Three copies of the weight are used in turn so that no launch finds it in the 256 MB Infinity Cache."""
+    import torch.nn.functional as F
+    v, k = 151936, 1024
+    ws = [(torch.randn(v, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(3)]
+    packed = [ops.lmhead_pack(w) for w in ws]
+    for b in (1, 8, 16, 29, 32, 48, 64):
+        x = torch.randn(b, k, device=DEV).to(torch.bfloat16)
+        t = torch.full((b,), 0.6, device=DEV)
+        full = torch.full((b,), v, dtype=torch.int64, device=DEV)
+        ones, zeros = torch.ones(b, device=DEV), torch.zeros(b, device=DEV)
+        out = torch.zeros(b, dtype=torch.int64, device=DEV)
+        lws = ops.lmhead_workspace(b, DEV)
+        sws = ops.sample_workspace(b, DEV)
+        i = [0]
+
+        def fused():
+            i[0] += 1
+            ops.lmhead_sample(packed[i[0] % 3], v, x, t, 0, v, 1, i[0], ws=lws, out=out)
+
+        def two():
+            i[0] += 1
+            ops.sample(F.linear(x, ws[i[0] % 3]), t, full, ones, zeros, 1, i[0], out=out, ws=sws)
+
+        def gemm():
+            i[0] += 1
+            F.linear(x, ws[i[0] % 3])
+
+        tf, tt, tg = timed(fused, args.reps), timed(two, args.reps), timed(gemm, args.reps)
+        print(json.dumps({"kernel": "lmhead_sample", "B": b, "fused_us": round(tf * 1e6, 1), "weight_GBps": round(v * k * 2 / tf / 1e9),
+                          "linear_plus_sample_us": round(tt * 1e6, 1), "linear_alone_us": round(tg * 1e6, 1)}))
+
+
 def cmd_linear(args):
     """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
     import torch.nn.functional as F
@@ -262,7 +296,7 @@ def cmd_linear(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm"])
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead"])
     ap.add_argument("--every", type=int, default=8)
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
@@ -272,4 +306,4 @@ if __name__ == "__main__":
     ap.add_argument("--uniform-len", type=int, default=0)
     ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
-    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear}[a.cmd](a)
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear, "lmhead": cmd_lmhead}[a.cmd](a)
