@@ -288,8 +288,9 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
  * pieces are in matrix-core operand order (nvx_lmhead_packed_elems() elements; rows past n_rows are zeros), so that
  * the kernel's loads are whole 1 KB lines that go straight into operand registers.
  *
- * nvx_lmhead_sample: x rows x_row_stride elements apart, batch <= nvx_lmhead_max_rows() (the batch stays in the LDS
- * of every compute unit), k = 1024.  Row r of W is token vocab_offset + r of a vocabulary of `vocab` tokens (a
+ * nvx_lmhead_sample: x rows x_row_stride elements apart, batch <= nvx_lmhead_max_rows(), k = 1024.  The batch stays in
+ * the LDS of every compute unit, nvx_lmhead_rows_per_pass() rows at a time: a taller batch takes one pass over the
+ * weight per such group of rows (measured on Qwen3-0.6B: one pass beats the projection + sampler, two passes do not).  Row r of W is token vocab_offset + r of a vocabulary of `vocab` tokens (a
  * tensor-parallel rank passes its shard; tokens >= vocab are padding and never drawn).  Every logit is rounded to the
  * 16-bit format, as the projection would have stored it; the draw is nvx_sample's (same noise per (seed, offset,
  * row, token), same tie rule; temperature <= 0: arg-max), so key_out / out_ids equal what nvx_sample_shard /
@@ -298,6 +299,7 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
  * logits_row_stride >= n_rows padded to 16 elements), if not NULL, receives the rounded logits.
  * ws: >= nvx_lmhead_ws_bytes(batch) bytes, 8-byte aligned.  No allocation, no host sync, capturable. */
 int64_t nvx_lmhead_max_rows(void);
+int64_t nvx_lmhead_rows_per_pass(void);
 int64_t nvx_lmhead_packed_elems(int64_t n_rows, int64_t k);
 int64_t nvx_lmhead_ws_bytes(int64_t batch);
 int nvx_lmhead_pack(const void* w, int64_t n_rows, int64_t k, void* packed, nvx_stream_t stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "nvx_peer_status": (_c_i32, [_c_vp]),
     "nvx_peer_destroy": (_c_i32, [_c_vp]),
     "nvx_lmhead_max_rows": (_c_i64, []),
+    "nvx_lmhead_rows_per_pass": (_c_i64, []),
     "nvx_lmhead_packed_elems": (_c_i64, [_c_i64, _c_i64]),
     "nvx_lmhead_ws_bytes": (_c_i64, [_c_i64]),
     "nvx_lmhead_pack": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),

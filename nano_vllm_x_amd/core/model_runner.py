@@ -31,6 +31,11 @@ from .common import ForwardBatch, ForwardMode
 from .hip_graph import HIPGraph, decode_batch_ladder
 from .kv_cache import KVCachePool
 
+# Largest step whose LM head + draw go through ops.lmhead_sample: it takes one pass over the weight per 64 rows, and from
+# the second pass on the library projection + sampler is the faster pair (Qwen3-0.6B, us: 59 vs 87 at 29 rows, 72 vs 97 at
+# 64, 137 vs 119 at 123; tools/kernel_bench.py lmhead)
+LMHEAD_FUSED_MAX_ROWS = int(os.environ.get("NVX_LMHEAD_FUSED_MAX_ROWS", "64"))
+
 _DTYPES = {"half": torch.float16, "float16": torch.float16, "float": torch.float32, "float32": torch.float32,
            "bfloat16": torch.bfloat16}
 
@@ -107,7 +112,7 @@ class ModelRunner:
             w = self.model.lm_head.weight
             self._lmhead_packed = ops.lmhead_pack(w.detach())
             self._lmhead_rows = w.shape[0]
-            self._lmhead_ws = ops.lmhead_workspace(ops.lmhead_max_rows(), self.device)
+            self._lmhead_ws = ops.lmhead_workspace(max(self.max_bs, 1), self.device)
         # tensor-parallel ranks: all-reduces of decode-sized tensors go peer to peer (set up and proven here, before
         # the decode graph is captured; every rank falls back to the library all-reduce together if it cannot be)
         tpd.init_peer_allreduce(self.max_bs, cfg.hidden_size, self.dtype, self.device)
@@ -247,7 +252,7 @@ class ModelRunner:
         t0 = time.perf_counter()
         temperatures, min_ps, top_ps, top_ks = self.prepare_sampling_params(batch)
         n = batch.num_seqs
-        if (self._lmhead_packed is not None and self.pp_size == 1 and self._sp_unfiltered and n <= min(self.max_bs, ops.lmhead_max_rows())
+        if (self._lmhead_packed is not None and self.pp_size == 1 and self._sp_unfiltered and n <= min(self.max_bs, LMHEAD_FUSED_MAX_ROWS)
                 and (self.tp_size == 1 or self.shard_sampling)):
             # LM head and draw in one pass over this rank's rows of the weight; tensor-parallel ranks exchange one 64-bit key
             # per row, as in the sharded path below

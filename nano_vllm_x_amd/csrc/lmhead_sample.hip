@@ -20,7 +20,8 @@
 
 namespace NVX_NS {
 
-#define LMH_MAX_ROWS 64
+#define LMH_MAX_ROWS 64      // rows of one pass: what the LDS of a compute unit holds as operands
+#define LMH_MAX_BATCH 1024   // rows of one call (ceil(batch / 64) passes over the weight)
 
 __device__ __forceinline__ nvx_u32x4 lmh_stream16(const nvx_u32x4* p) { return __builtin_nontemporal_load(p); }
 
@@ -43,9 +44,11 @@ __global__ __launch_bounds__(256) void lmhead_pack_kernel(const uint16_t* __rest
 
 template <int MT, int K>
 __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
-    const nvx_u32x4* __restrict__ wp, const uint16_t* __restrict__ x, int64_t x_stride, int m_rows,
+    const nvx_u32x4* __restrict__ wp, const uint16_t* __restrict__ x, int64_t x_stride, int m_rows, int row0,
     const float* __restrict__ temps, int n_tiles, int tok0, int tok_end, uint64_t seed, uint64_t offset,
     unsigned long long* __restrict__ winners, uint16_t* __restrict__ logits_out, int64_t logits_stride) {
+    // x, temps, winners and logits_out point at THIS pass's rows; row0 is the index of the first of them in the batch
+    // (the noise of a row is keyed by its index in the whole batch)
     constexpr int KS = K / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lmh_smem[];
     nvx_u32x4* xs = reinterpret_cast<nvx_u32x4*>(lmh_smem);   // [MT][KS][64]: the batch rows as B operands
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
                 }
                 uint4 r = make_uint4(0, 0, 0, 0);
 #ifndef LMH_NO_EPI
-                if (!greedy[mt]) r = philox4x32_10(make_uint4((uint32_t)((tok0 + base) >> 2), (uint32_t)m, (uint32_t)offset, (uint32_t)(offset >> 32)), key);
+                if (!greedy[mt]) r = philox4x32_10(make_uint4((uint32_t)((tok0 + base) >> 2), (uint32_t)(row0 + m), (uint32_t)offset, (uint32_t)(offset >> 32)), key);
 #endif
                 const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -199,7 +202,8 @@ static int lmh_workgroups() {
 }
 
 #ifndef NVX_F16   // format-independent helpers: defined by the bfloat16 build only
-extern "C" int64_t nvx_lmhead_max_rows(void) { return LMH_MAX_ROWS; }
+extern "C" int64_t nvx_lmhead_max_rows(void) { return LMH_MAX_BATCH; }
+extern "C" int64_t nvx_lmhead_rows_per_pass(void) { return LMH_MAX_ROWS; }
 extern "C" int64_t nvx_lmhead_packed_elems(int64_t n_rows, int64_t k) { return ((n_rows + 15) / 16) * 16 * k; }
 extern "C" int64_t nvx_lmhead_ws_bytes(int64_t batch) { return (int64_t)1024 * (batch > 0 ? batch : 1) * 8; }
 
@@ -224,8 +228,8 @@ extern "C" int NVX_ENTRY(nvx_lmhead_sample)(const void* w_packed, int64_t n_rows
     NVX_REQUIRE(batch >= 0 && n_rows > 0 && vocab > 0 && vocab_offset >= 0, NVX_EINVAL, "%s: bad size", who);
     if (batch == 0) return NVX_OK;
     NVX_REQUIRE(w_packed && x && temperatures && ws && (key_out || out_ids), NVX_EINVAL, "%s: null pointer", who);
-    NVX_REQUIRE(batch <= LMH_MAX_ROWS, NVX_ENOSPACE, "%s: %lld rows; the batch must fit the LDS of a compute unit (at most %d rows)", who,
-                (long long)batch, LMH_MAX_ROWS);
+    NVX_REQUIRE(batch <= LMH_MAX_BATCH, NVX_ENOSPACE, "%s: %lld rows (at most %d; they are taken %d at a time, one pass over the weight each)",
+                who, (long long)batch, LMH_MAX_BATCH, LMH_MAX_ROWS);
     NVX_REQUIRE(k == 1024, NVX_EUNSUPPORTED, "%s: built for hidden size 1024 (got %lld)", who, (long long)k);
     NVX_REQUIRE(vocab_offset % 4 == 0 && vocab_offset + n_rows <= 0x7fffffffll && vocab <= 0x7fffffffll, NVX_EINVAL,
                 "%s: the rows must start at a multiple of 4 tokens and token ids stay below 2^31", who);
@@ -242,27 +246,35 @@ extern "C" int NVX_ENTRY(nvx_lmhead_sample)(const void* w_packed, int64_t n_rows
                 "%s: workspace too small (%lld < %lld bytes)", who, (long long)ws_bytes, (long long)((int64_t)grid * batch * 8));
     const int64_t end = vocab_offset + n_rows < vocab ? vocab_offset + n_rows : vocab;
     hipStream_t st = (hipStream_t)stream;
-    const int mt = (int)((batch + 15) / 16);
+    // more rows than a compute unit holds: passes of equal height (two passes of 62 and 61 rows, not 64 and 59)
+    const int passes = (int)((batch + LMH_MAX_ROWS - 1) / LMH_MAX_ROWS);
+    const int per_pass = (int)((batch + passes - 1) / passes);
 #define NVX_LMH(MTV)                                                                                                                       \
     do {                                                                                                                                   \
         const size_t lds = (size_t)MTV * (1024 / 32) * 1024;                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MTV, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((lmhead_sample_kernel<MTV, 1024>), dim3((unsigned)grid), dim3(256), lds, st, (const nvx_u32x4*)w_packed,         \
-                           (const uint16_t*)x, x_row_stride, (int)batch, temperatures, n_tiles, (int)vocab_offset, (int)end, seed, offset, \
-                           (unsigned long long*)ws, (uint16_t*)logits_out, logits_row_stride);                                             \
+                           (const uint16_t*)x + (int64_t)r0 * x_row_stride, x_row_stride, rows, r0, temperatures + r0, n_tiles,             \
+                           (int)vocab_offset, (int)end, seed, offset, (unsigned long long*)ws + (int64_t)grid * r0,                        \
+                           logits_out ? (uint16_t*)logits_out + (int64_t)r0 * logits_row_stride : (uint16_t*)nullptr, logits_row_stride);  \
     } while (0)
-    switch (mt) {
-        case 1: NVX_LMH(1); break;
-        case 2: NVX_LMH(2); break;
-        case 3: NVX_LMH(3); break;
-        default: NVX_LMH(4); break;
+    for (int r0 = 0; r0 < (int)batch; r0 += per_pass) {
+        const int rows = (int)batch - r0 < per_pass ? (int)batch - r0 : per_pass;
+        switch ((rows + 15) / 16) {
+            case 1: NVX_LMH(1); break;
+            case 2: NVX_LMH(2); break;
+            case 3: NVX_LMH(3); break;
+            default: NVX_LMH(4); break;
+        }
+        int rc = nvx_check_launch(who);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lmhead_pick_kernel, dim3((unsigned)rows), dim3(64), 0, st, (const unsigned long long*)ws + (int64_t)grid * r0, grid,
+                           rows, key_out ? (unsigned long long*)key_out + r0 : (unsigned long long*)nullptr, out_ids ? out_ids + r0 : nullptr);
+        rc = nvx_check_launch("nvx_lmhead_sample(pick)");
+        if (rc) return rc;
     }
 #undef NVX_LMH
-    int rc = nvx_check_launch(who);
-    if (rc) return rc;
-    hipLaunchKernelGGL(lmhead_pick_kernel, dim3((unsigned)batch), dim3(64), 0, st, (const unsigned long long*)ws, grid,
-                       (int)batch, (unsigned long long*)key_out, out_ids);
-    return nvx_check_launch("nvx_lmhead_sample(pick)");
+    return NVX_OK;
 }
 
 }  // namespace NVX_NS

@@ -110,7 +110,7 @@ def test_every_kernel_entry_point_has_a_custom_op():
              "nvx_lmhead_sample": "lmhead_sample"}
     helpers = {"nvx_abi_version", "nvx_last_error", "nvx_linear_decode_splits", "nvx_decode_plan_ws_ints", "nvx_decode_partial_ws_floats",
                "nvx_prefill_plan_ws_ints", "nvx_sample_ws_bytes", "nvx_paged_decode_noalloc_max_batch",
-               "nvx_lmhead_max_rows", "nvx_lmhead_packed_elems", "nvx_lmhead_ws_bytes",
+               "nvx_lmhead_max_rows", "nvx_lmhead_rows_per_pass", "nvx_lmhead_packed_elems", "nvx_lmhead_ws_bytes",
                # start-up calls of the direct-peer exchange (allocation, handle exchange, status, teardown): host side
                "nvx_peer_exchange_bytes", "nvx_peer_create", "nvx_peer_export", "nvx_peer_import", "nvx_peer_status", "nvx_peer_destroy"}
     # the float16 entry points have no operator of their own: the operator of the bfloat16 one picks them by tensor dtype

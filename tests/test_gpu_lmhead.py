@@ -77,7 +77,7 @@ def _case(ops, b, n_rows, dtype, seed, temps=None, vocab=None):
     return w, x, t, want
 
 
-@pytest.mark.parametrize("b", [1, 5, 16, 17, 29, 48, 64])
+@pytest.mark.parametrize("b", [1, 5, 16, 17, 29, 48, 64, 65, 123, 200])
 def test_fused_lm_head_draws_the_token_of_the_unfused_path(ops, b):
     _case(ops, b, 4096, torch.bfloat16, 100 + b)
 
@@ -108,10 +108,10 @@ def test_shards_of_the_vocabulary_pick_the_token_of_the_whole_row(ops):
 def test_limits_are_refused_on_the_host(ops):
     w = torch.zeros(64, 1024, dtype=torch.bfloat16, device=DEV)
     packed = ops.lmhead_pack(w)
-    t = torch.ones(65, device=DEV)
+    t = torch.ones(1025, device=DEV)
     with pytest.raises(RuntimeError):
-        ops.lmhead_sample(packed, 64, torch.zeros(65, 1024, dtype=torch.bfloat16, device=DEV), t, 0, 64, 1, 1)
+        ops.lmhead_sample(packed, 64, torch.zeros(1025, 1024, dtype=torch.bfloat16, device=DEV), t, 0, 64, 1, 1)
     with pytest.raises(RuntimeError):      # another hidden size than the kernel is built for
         ops.lmhead_sample(ops.lmhead_pack(torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV)), 64,
                           torch.zeros(4, 512, dtype=torch.bfloat16, device=DEV), t[:4], 0, 64, 1, 1)
-    assert ops.lmhead_max_rows() == 64
+    assert ops.lmhead_max_rows() == 1024

@@ -238,7 +238,7 @@ def cmd_lmhead(args):
     v, k = 151936, 1024
     ws = [(torch.randn(v, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(3)]
     packed = [ops.lmhead_pack(w) for w in ws]
-    for b in (1, 8, 16, 29, 32, 48, 64):
+    for b in (1, 8, 16, 29, 32, 48, 64, 96, 123, 128, 192, 256):
         x = torch.randn(b, k, device=DEV).to(torch.bfloat16)
         t = torch.full((b,), 0.6, device=DEV)
         full = torch.full((b,), v, dtype=torch.int64, device=DEV)
