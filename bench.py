@@ -413,14 +413,14 @@ def main():
     eng = llm.engine
 
     for _ in range(args.warmup):
-        eng.reset()
+        llm.reset()
         asyncio.run(one_pass(llm, prompts, max_tokens))
     sync_all(world)
     stats0 = dict(eng.model_runner.stats)
     t0 = time.perf_counter()
     generated = 0
     for _ in range(args.steps):
-        eng.reset()
+        llm.reset()
         generated += asyncio.run(one_pass(llm, prompts, max_tokens))
     sync_all(world)
     wall = time.perf_counter() - t0
@@ -433,7 +433,7 @@ def main():
     plain_wall = None
     if eng.run_ahead and args.plain_pass:
         eng.run_ahead = False
-        eng.reset()
+        llm.reset()
         sync_all(world)
         t1 = time.perf_counter()
         asyncio.run(one_pass(llm, prompts, max_tokens))

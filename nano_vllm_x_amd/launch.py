@@ -56,6 +56,60 @@ def run_ranks(nproc: int, script: str, script_args: Sequence[str] = (), env=None
     return subprocess.run(cmd, env=child_env).returncode
 
 
+class EngineFollowers:
+    """Ranks 1 .. world-1 of an engine whose rank 0 lives in THIS process (see follower.py for the protocol).  Started
+    before this process touches the GPU; afterwards this process is rank 0 of the same rendezvous."""
+
+    def __init__(self, world: int, engine_kwargs: dict, env=None, port: Optional[int] = None, python: Optional[str] = None):
+        import json
+
+        self._json = json
+        self.world = world
+        port = port or free_port()
+        base = dict(os.environ if env is None else env)
+        base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        base.update(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        base["PYTHONPATH"] = root + (os.pathsep + base["PYTHONPATH"] if base.get("PYTHONPATH") else "")
+        self.procs = []
+        for rank in range(1, world):
+            e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+            self.procs.append(subprocess.Popen([python or sys.executable, "-m", "nano_vllm_x_amd.follower"], env=e, stdin=subprocess.PIPE,
+                                               text=True, bufsize=1))
+        # this process becomes rank 0 of the same job
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          LOCAL_WORLD_SIZE=str(world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self.send({"op": "init", "kwargs": engine_kwargs})
+
+    def send(self, event: dict):
+        line = self._json.dumps(event) + "\n"
+        for rank, p in enumerate(self.procs, start=1):
+            if p.poll() is not None:
+                raise RuntimeError(f"rank {rank} of the engine has exited with code {p.returncode}")
+            try:
+                p.stdin.write(line)
+                p.stdin.flush()
+            except (BrokenPipeError, OSError) as e:
+                raise RuntimeError(f"rank {rank} of the engine is gone ({e})") from None
+
+    def close(self, timeout: float = 60.0):
+        for p in self.procs:
+            try:
+                if p.poll() is None:
+                    p.stdin.write(self._json.dumps({"op": "shutdown"}) + "\n")
+                    p.stdin.flush()
+                p.stdin.close()
+            except (BrokenPipeError, OSError, ValueError):
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        self.procs = []
+
+
 def require_launcher(world: int, what: str = "LLM"):
     """Fail at once, with the remedy, when a job of several ranks is asked for from a process nobody launched as a
     rank: joining the process group would otherwise wait for peers that were never started."""

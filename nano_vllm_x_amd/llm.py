@@ -8,6 +8,7 @@ so a token travels from the sampler to the caller without pickling.
 from __future__ import annotations
 
 import asyncio
+import dataclasses
 import os
 import uuid
 from typing import AsyncGenerator, Optional
@@ -47,19 +48,29 @@ class LLM:
                  enforce_eager: bool = False, context_len: int = 2048, kv_cache_size: Optional[int] = None, seed: int = 0,
                  prefix_reuse: bool = False, max_prefill_tokens: Optional[int] = None, stop_at_context_len: bool = False,
                  chunked_prefill: bool = False, run_ahead: bool = False):
+        kwargs = dict(model=model, gpu_memory_utilization=gpu_memory_utilization, max_bs=max_bs, tp_size=tp_size, pp_size=pp_size,
+                      nccl_port=nccl_port, device_ids=device_ids, enforce_eager=enforce_eager, context_len=context_len,
+                      kv_cache_size=kv_cache_size, seed=seed, prefix_reuse=prefix_reuse, max_prefill_tokens=max_prefill_tokens,
+                      stop_at_context_len=stop_at_context_len, chunked_prefill=chunked_prefill, run_ahead=run_ahead)
+        self.followers = None
         if tp_size * pp_size > 1:
-            # The reference spawns its worker processes here (core/executor.py:32-49).  This engine is SPMD: the
-            # caller's script runs once per GPU (launch.run_ranks / torch.distributed.run).  A process that was not
-            # started as a rank is told so now, before any model or device work, not after a rendezvous time-out.
+            # The reference spawns one worker process per GPU here (core/executor.py:32-49).  This engine is SPMD: every
+            # rank runs the same loop.  Inside a job that a launcher started (launch.run_ranks, torch.distributed.run) this
+            # process is simply its rank; from a plain process the other ranks are started now -- before this process
+            # touches the GPU -- and told, event by event, what this process's caller does (launch.EngineFollowers).
             import torch.distributed as dist
 
-            from .launch import require_launcher
-            if not dist.is_initialized():
-                require_launcher(tp_size * pp_size, f"LLM(tp_size={tp_size}, pp_size={pp_size})")
-        self.engine = Engine(model, gpu_memory_utilization, max_bs, tp_size, pp_size, nccl_port, device_ids,
-                             enforce_eager, context_len, kv_cache_size=kv_cache_size, seed=seed, prefix_reuse=prefix_reuse,
-                             max_prefill_tokens=max_prefill_tokens, stop_at_context_len=stop_at_context_len,
-                             chunked_prefill=chunked_prefill, run_ahead=run_ahead)
+            from .launch import EngineFollowers, launcher_env_present, require_launcher
+            if not dist.is_initialized() and not launcher_env_present():
+                if os.environ.get("NVX_SPAWN_RANKS", "1") == "0":
+                    require_launcher(tp_size * pp_size, f"LLM(tp_size={tp_size}, pp_size={pp_size})")
+                self.followers = EngineFollowers(tp_size * pp_size, kwargs)
+        try:
+            self.engine = Engine(**kwargs)
+        except BaseException:
+            if self.followers is not None:
+                self.followers.close(timeout=5.0)
+            raise
         self.tokenizer = init_tokenizer(model)
         self.request_states: dict = {}
         self._pump: Optional[asyncio.Task] = None
@@ -86,6 +97,8 @@ class LLM:
                 # waits for the step in flight (or runs one) and queues the next step before this one's tokens
                 # are handed out: queue wake-ups, detokenisation and the consumers' own code then run while
                 # the device is busy
+                if self.followers is not None:
+                    self.followers.send({"op": "step"})
                 outs = eng.step_overlapped()
                 for out in outs:
                     q = self.request_states.get(out.seq_id)
@@ -129,6 +142,8 @@ class LLM:
                 params.eos_token_id = self.tokenizer.eos_token_id
             q: asyncio.Queue = asyncio.Queue()
             self.request_states[sequence_id] = q
+            if self.followers is not None:
+                self.followers.send({"op": "add", "id": sequence_id, "ids": token_ids, "params": dataclasses.asdict(params)})
             self.engine.add_sequence(sequence_id=sequence_id, prompt_token_ids=token_ids, sampling_params=params)
             self._ensure_pump()
             while True:
@@ -144,10 +159,23 @@ class LLM:
 
     def abort(self, sequence_id: str):
         if sequence_id in self.request_states:
+            if self.followers is not None:
+                self.followers.send({"op": "abort", "id": sequence_id})
             self.engine.abort_sequence(sequence_id)
             del self.request_states[sequence_id]
+
+    def reset(self):
+        """Forget every sequence and cached prefix on every rank (between passes of a benchmark)."""
+        if self.followers is not None:
+            self.followers.send({"op": "reset"})
+        self.engine.reset()
 
     def shutdown(self):
         if self._pump is not None:
             self._pump.cancel()
+        if self.followers is not None:
+            self.followers.send({"op": "shutdown"})     # the ranks leave the process group together
         self.engine.shutdown()
+        if self.followers is not None:
+            self.followers.close()
+            self.followers = None

@@ -65,6 +65,11 @@ PRESETS = {
 }
 
 
+# NVX_EXTRA_PRESETS: a JSON object {name: {field: value}} of further geometries by name -- how a test or a rehearsal gives every
+# rank of a job (the variable is inherited by the ranks it starts) a small model without a directory on disk
+PRESETS.update(json.loads(os.environ.get("NVX_EXTRA_PRESETS") or "{}"))
+
+
 def load_config(model: str) -> Qwen3Config:
     """`model` is a directory holding config.json, or the name of a preset (possibly as the last
     path component, e.g. "../Qwen3-0.6B" as the reference's bench.py passes it)."""

@@ -70,8 +70,11 @@ def test_run_ranks_starts_every_rank_and_returns_the_exit_code(tmp_path):
 
 
 def test_several_ranks_without_a_launcher_fail_at_once(monkeypatch):
+    """With NVX_SPAWN_RANKS=0 (the caller starts its own ranks, or none may be started) a process that is no rank is told
+    so at once; by default LLM starts the other ranks itself (next test)."""
     for v in launch.RENDEZVOUS_VARS:
         monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("NVX_SPAWN_RANKS", "0")
     from nano_vllm_x_amd import LLM
     from nano_vllm_x_amd import distributed as tpd
 
@@ -114,3 +117,61 @@ def test_bench_relaunches_itself_for_several_gpus(tmp_path, monkeypatch):
     assert cmd[-8:] == ["--gpus", "2", "--steps", "1", "--warmup", "0", "--num-seqs", "48"]
     assert os.path.basename(cmd[-9]) == "bench.py"
     assert "WORLD_SIZE" not in calls["env"] and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_engine_followers_replay_the_callers_events_in_order_on_every_rank(tmp_path, monkeypatch):
+    """LLM(tp_size * pp_size > 1) from a plain process starts ranks 1.. itself and tells them what its caller does: the same
+    constructor arguments, then every add / abort / step / reset in the order they happened (the reference spawns its
+    workers and ships them every batch, core/executor.py:32-49,86-97).  Driven here with a stand-in engine, no device."""
+    import dataclasses
+    import json
+
+    from nano_vllm_x_amd.core.common import SamplingParams
+
+    log = tmp_path / "events"
+    env = _clean_env()
+    env.update(NVX_FOLLOWER_ENGINE="follower_standin:RecordingEngine", NVX_STANDIN_LOG=str(log),
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", ""))
+    saved = {v: os.environ.get(v) for v in launch.RENDEZVOUS_VARS + ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    try:
+        kwargs = dict(model="Qwen3-0.6B", tp_size=3, max_bs=8, device_ids=None, run_ahead=True)
+        f = launch.EngineFollowers(3, kwargs, env=env)
+        assert os.environ["RANK"] == "0" and os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        sp = SamplingParams(temperature=0.6, ignore_eos=True, max_new_tokens=5)
+        f.send({"op": "add", "id": "a", "ids": [1, 2, 3], "params": dataclasses.asdict(sp)})
+        f.send({"op": "step"})
+        f.send({"op": "add", "id": "b", "ids": [4], "params": dataclasses.asdict(sp)})
+        f.send({"op": "step"})
+        f.send({"op": "abort", "id": "a"})
+        f.send({"op": "reset"})
+        procs = list(f.procs)
+        f.close(timeout=60)
+        assert all(p.returncode == 0 for p in procs)
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
+    want = ["init", "add", "step", "add", "step", "abort", "reset", "shutdown"]
+    for rank in (1, 2):
+        recs = [json.loads(line) for line in open(f"{log}.{rank}")]
+        assert [r["call"] for r in recs] == want
+        assert recs[0]["kwargs"] == kwargs and recs[0]["world"] == "3" and recs[0]["master"] == "127.0.0.1"
+        assert recs[1] == {"call": "add", "id": "a", "ids": [1, 2, 3], "temperature": 0.6, "max_new_tokens": 5, "ignore_eos": True}
+    # a rank that has died is reported at the next event, not by a hung collective
+    bad_env = dict(env, NVX_FOLLOWER_ENGINE="follower_standin:Missing")
+    try:
+        g = launch.EngineFollowers(2, {}, env=bad_env)
+        time.sleep(3.0)
+        with pytest.raises(RuntimeError, match="rank 1 of the engine"):
+            for _ in range(50):
+                g.send({"op": "step"})
+                time.sleep(0.1)
+        g.close(timeout=5)
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
