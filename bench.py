@@ -504,10 +504,13 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if graph_broken:
-        # hipGraph decode was asked for and is not what (all of) the timed steps ran on: the line above says what did
-        # run, and the run fails so that the number cannot pass for a hipGraph one
+        # hipGraph decode was asked for and is not what (all of) the timed steps ran on: the line above says what did run
+        # (`config.decode`).  On one GPU that is a defect of this tree and the run fails, so that the number cannot pass for a
+        # hipGraph one; on several ranks a collective library that refuses capture is a property of the machine: the line
+        # stands as measured (eager decode, said so) unless NVX_REQUIRE_GRAPH=1 asks for the failure.
         print(f"bench.py: decode ran as '{decode_mode}' although hipGraph was requested", file=sys.stderr, flush=True)
-        raise SystemExit(3)
+        if world == 1 or os.environ.get("NVX_REQUIRE_GRAPH") == "1":
+            raise SystemExit(3)
 
 
 if __name__ == "__main__":

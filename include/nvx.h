@@ -41,7 +41,7 @@ typedef void* nvx_stream_t;
  *   2: nvx_decode_step_setup gained `prev_ids`.
  *   3: float16 entry points (`*_f16`) added.
  *   4: direct-peer all-reduce (`nvx_peer_*`) and sharded sampling (`nvx_sample_shard`, `nvx_sample_pick`) added. */
-#define NVX_ABI_VERSION 5
+#define NVX_ABI_VERSION 6
 
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
@@ -309,6 +309,19 @@ int nvx_lmhead_sample(const void* w_packed, int64_t n_rows, int64_t k, const voi
                       int64_t* out_ids, void* logits_out, int64_t logits_row_stride, nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Projection of a decode step over a weight too large for nvx_linear_decode's weight-stationary kernel (tens of MB: the
+ * projections of Qwen3-8B and larger; the reference's F.linear, nanovllmx/layers/linear.py:73,169,276): the weight, packed
+ * by nvx_lmhead_pack (k a multiple of 1024), is streamed once with the batch's rows (m <= 64) resident in LDS, one
+ * 1024-wide slice of k per workgroup.  partials (k / 1024, m, n) fp32 receives each slice's share of x . W^T; the
+ * consumer sums them: nvx_rmsnorm_splitk after a row-parallel projection, or nvx_splitk_sum -- (rows, n) in the 16-bit
+ * format, or with silu_mul != 0 the SiluAndMul (nanovllmx/layers/activation.py:15-18) of a [gate | up] projection,
+ * (rows, n / 2), the sum rounded to the 16-bit format first as the unsplit projection would have stored it. */
+int nvx_linear_stream(const void* w_packed, int64_t n, int64_t k, const void* x, int64_t x_row_stride, int64_t m,
+                      float* partials, nvx_stream_t stream);
+int nvx_splitk_sum(const float* partials, int n_splits, int64_t rows, int64_t n, int silu_mul, void* y,
+                   nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Tensor-parallel all-reduce of a decode step, over memory the peers have mapped, fused with the
  * RMSNorm that follows it.  Replaces the NCCL all-reduce behind the row-parallel linears and the
  * vocab-parallel embedding (nanovllmx/distributed/communication_op.py:41-52,153-156, called from
@@ -401,6 +414,10 @@ int nvx_paged_prefill_f16(const void* q, int64_t q_row_stride, const void* k_cac
 int nvx_peer_allreduce_norm_f16(void* comm, const void* x, int64_t x_row_stride, const void* residual,
                             const void* weight, void* y, void* residual_out, int64_t rows,
                             int64_t hidden, float eps, nvx_stream_t stream);
+int nvx_linear_stream_f16(const void* w_packed, int64_t n, int64_t k, const void* x, int64_t x_row_stride, int64_t m,
+                          float* partials, nvx_stream_t stream);
+int nvx_splitk_sum_f16(const float* partials, int n_splits, int64_t rows, int64_t n, int silu_mul, void* y,
+                       nvx_stream_t stream);
 int nvx_lmhead_sample_f16(const void* w_packed, int64_t n_rows, int64_t k, const void* x, int64_t x_row_stride,
                           int64_t batch, const float* temperatures, int64_t vocab_offset, int64_t vocab,
                           uint64_t seed, uint64_t offset, void* ws, int64_t ws_bytes, uint64_t* key_out,

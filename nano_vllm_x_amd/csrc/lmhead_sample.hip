@@ -170,6 +170,77 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same stream for a PROJECTION of a decode step whose weight is too large for the weight-stationary skinny kernel
+// (tens of MB: the projections of Qwen3-8B and larger): y (m, n) = x (m, k) . W^T (n, k), k a multiple of 1024.  A
+// workgroup keeps ONE 1024-wide slice of the batch's rows in LDS for its whole life and streams the tiles of that slice
+// (32 KB each, same packed layout as the LM head: a slice of a tile is contiguous), so what it leaves is its slice's
+// share of the products: fp32 partials (k / 1024, m, n) that the consumer sums -- nvx_rmsnorm_splitk after a
+// row-parallel projection, nvx_splitk_sum (plain, or with SiluAndMul) otherwise.
+template <int MT>
+__global__ __launch_bounds__(256, 1) void linear_stream_kernel(
+    const nvx_u32x4* __restrict__ wp, const uint16_t* __restrict__ x, int64_t x_stride, int m_rows, int n_tiles, int n_cols,
+    int n_slices, float* __restrict__ partials) {
+    constexpr int KS = 32;   // k-steps of a 1024-wide slice
+    extern __shared__ __attribute__((aligned(16))) unsigned char lmh_smem[];
+    nvx_u32x4* xs = reinterpret_cast<nvx_u32x4*>(lmh_smem);   // [MT][KS][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int quarter = lane >> 4, l16 = lane & 15;
+    const int slice = blockIdx.x % n_slices, group = blockIdx.x / n_slices, n_groups = gridDim.x / n_slices;
+
+    for (int i = tid; i < MT * 16 * 128; i += 256) {
+        const int m = i >> 7, c = i & 127;
+        nvx_u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < m_rows) v = *reinterpret_cast<const nvx_u32x4*>(x + (int64_t)m * x_stride + slice * 1024 + c * 8);
+        xs[((m >> 4) * KS + (c >> 2)) * 64 + (c & 3) * 16 + (m & 15)] = v;
+    }
+    __syncthreads();
+    if (group >= n_groups) return;   // (workgroups beyond a whole number of slice groups)
+
+    const int64_t tile_pitch = (int64_t)n_slices * KS * 64;            // 16-byte pieces per tile of 16 rows over all of k
+    const nvx_u32x4* base = wp + (int64_t)slice * KS * 64 + lane;
+    const int stride_tiles = n_groups * 4;
+    int tile = group * 4 + wave;
+    float* out = partials + (int64_t)slice * m_rows * n_cols;
+
+    nvx_u32x4 a[KS];
+    if (tile < n_tiles) {
+        const nvx_u32x4* wt = base + (int64_t)tile * tile_pitch;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[kk] = lmh_stream16(wt + kk * 64);
+    }
+    while (tile < n_tiles) {
+        const int next = tile + stride_tiles;
+        const nvx_u32x4* wn = base + (int64_t)(next < n_tiles ? next : tile) * tile_pitch;
+        nvx_f32x4 acc[MT];
+        nvx_u32x4 b[MT], bn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt] = nvx_f32x4{0.f, 0.f, 0.f, 0.f}; b[mt] = xs[(mt * KS) * 64 + lane]; }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) bn[mt] = xs[(mt * KS + kk + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_16x16x32_h16(a[kk], b[mt], acc[mt]);
+            a[kk] = lmh_stream16(wn + kk * 64);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = bn[mt];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this lane: columns tile * 16 + 4 q .. + 3 of batch row mt * 16 + l16
+        const int col = tile * 16 + quarter * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + l16;
+            if (m < m_rows && col < n_cols)
+                *reinterpret_cast<nvx_f32x4*>(out + (int64_t)m * n_cols + col) = acc[mt];
+        }
+        tile = next;
+    }
+}
+
 // per row: the best of the workgroups' keys, as a key and / or as a token id.  One wave per row: the keys of a row are
 // n_sets independent loads (a loop over them in one thread is n_sets memory round trips in a row).
 __global__ __launch_bounds__(64) void lmhead_pick_kernel(const unsigned long long* __restrict__ winners, int n_sets, int batch,
@@ -219,6 +290,42 @@ extern "C" int nvx_lmhead_pack(const void* w, int64_t n_rows, int64_t k, void* p
     return nvx_check_launch("nvx_lmhead_pack");
 }
 #endif
+
+extern "C" int NVX_ENTRY(nvx_linear_stream)(const void* w_packed, int64_t n, int64_t k, const void* x, int64_t x_row_stride, int64_t m,
+                                            float* partials, nvx_stream_t stream) {
+    const char* who = "nvx_linear_stream";
+    NVX_REQUIRE(m >= 0 && n > 0 && k > 0, NVX_EINVAL, "%s: bad size", who);
+    if (m == 0) return NVX_OK;
+    NVX_REQUIRE(w_packed && x && partials, NVX_EINVAL, "%s: null pointer", who);
+    NVX_REQUIRE(m <= LMH_MAX_ROWS, NVX_ENOSPACE, "%s: %lld rows; at most %d stay in the LDS of a compute unit", who, (long long)m, LMH_MAX_ROWS);
+    NVX_REQUIRE(k % 1024 == 0 && k <= 64 * 1024, NVX_EUNSUPPORTED, "%s: k must be a multiple of 1024, at most 65536 (got %lld)", who, (long long)k);
+    NVX_REQUIRE(n % 4 == 0, NVX_EUNSUPPORTED, "%s: n must be a multiple of 4 (got %lld)", who, (long long)n);
+    NVX_REQUIRE(x_row_stride % 8 == 0 && x_row_stride >= k && nvx_aligned16(x) && nvx_aligned16(w_packed) && nvx_aligned16(partials), NVX_EINVAL,
+                "%s: rows must be 16-byte aligned", who);
+    const int n_tiles = (int)((n + 15) / 16);
+    const int n_slices = (int)(k / 1024);
+    // a whole number of slice groups, one workgroup per compute unit where the tiles allow
+    int groups = lmh_workgroups() / n_slices;
+    if (groups < 1) groups = 1;
+    if (groups > (n_tiles + 3) / 4) groups = (n_tiles + 3) / 4;
+    const int grid = groups * n_slices;
+    hipStream_t st = (hipStream_t)stream;
+#define NVX_LST(MTV)                                                                                                                     \
+    do {                                                                                                                                 \
+        const size_t lds = (size_t)MTV * 32 * 1024;                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_stream_kernel<MTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((linear_stream_kernel<MTV>), dim3((unsigned)grid), dim3(256), lds, st, (const nvx_u32x4*)w_packed, (const uint16_t*)x, \
+                           x_row_stride, (int)m, n_tiles, (int)n, n_slices, partials);                                                   \
+    } while (0)
+    switch ((int)((m + 15) / 16)) {
+        case 1: NVX_LST(1); break;
+        case 2: NVX_LST(2); break;
+        case 3: NVX_LST(3); break;
+        default: NVX_LST(4); break;
+    }
+#undef NVX_LST
+    return nvx_check_launch(who);
+}
 
 extern "C" int NVX_ENTRY(nvx_lmhead_sample)(const void* w_packed, int64_t n_rows, int64_t k, const void* x, int64_t x_row_stride,
                                             int64_t batch, const float* temperatures, int64_t vocab_offset, int64_t vocab,

@@ -473,4 +473,49 @@ extern "C" int NVX_ENTRY(nvx_silu_mul)(const void* x, void* y, int64_t rows, int
     return nvx_check_launch("nvx_silu_mul");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sum of the fp32 partial products a K-split projection left behind, (splits, rows, n) -> 16-bit (rows, n); with SILU the
+// sum is a [gate | up] projection and the result is SiluAndMul of it, (rows, n / 2) -- the sum is rounded to the 16-bit
+// format first, as the unsplit projection would have stored it, then the same arithmetic as silu_mul_kernel.
+template <bool SILU>
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ partials, int n_splits, int rows, int n,
+                                                         uint16_t* __restrict__ y) {
+    const int out_cols = SILU ? n / 2 : n;
+    const int per_row = out_cols / 4;
+    const int64_t split_stride = (int64_t)rows * n;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < rows * per_row; id += gridDim.x * 256) {
+        const int r = id / per_row, c = (id % per_row) * 4;
+        const float* p = partials + (int64_t)r * n + c;
+        nvx_f32x4 g = *reinterpret_cast<const nvx_f32x4*>(p);
+        nvx_f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (SILU) u = *reinterpret_cast<const nvx_f32x4*>(p + out_cols);
+        for (int s = 1; s < n_splits; ++s) {
+            g += *reinterpret_cast<const nvx_f32x4*>(p + s * split_stride);
+            if (SILU) u += *reinterpret_cast<const nvx_f32x4*>(p + s * split_stride + out_cols);
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = SILU ? silu_h16(round_h16(g[j])) * round_h16(u[j]) : g[j];
+        *reinterpret_cast<uint2*>(y + (int64_t)r * out_cols + c) = make_uint2(pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3]));
+    }
+}
+
+extern "C" int NVX_ENTRY(nvx_splitk_sum)(const float* partials, int n_splits, int64_t rows, int64_t n, int silu_mul, void* y,
+                                         nvx_stream_t stream) {
+    NVX_REQUIRE(rows >= 0 && n > 0 && n_splits >= 1 && n_splits <= 64, NVX_EINVAL, "nvx_splitk_sum: bad size");
+    if (rows == 0) return NVX_OK;
+    NVX_REQUIRE(partials && y, NVX_EINVAL, "nvx_splitk_sum: null pointer");
+    NVX_REQUIRE(n % (silu_mul ? 8 : 4) == 0 && rows * n < 0x7fffffffll, NVX_EUNSUPPORTED,
+                "nvx_splitk_sum: n must be a multiple of %d and rows x n fit 31 bits", silu_mul ? 8 : 4);
+    NVX_REQUIRE(nvx_aligned16(partials) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0, NVX_EINVAL, "nvx_splitk_sum: alignment");
+    const int64_t work = rows * ((silu_mul ? n / 2 : n) / 4);
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (silu_mul)
+        hipLaunchKernelGGL(splitk_sum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, (int)rows, (int)n, (uint16_t*)y);
+    else
+        hipLaunchKernelGGL(splitk_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, (int)rows, (int)n, (uint16_t*)y);
+    return nvx_check_launch("nvx_splitk_sum");
+}
+
 }  // namespace NVX_NS

@@ -456,6 +456,39 @@ def lmhead_sample(packed, n_rows: int, x, temperatures, vocab_offset: int, vocab
     return out
 
 
+def linear_stream(x, packed, n: int, out=None):
+    """x (m, k) 16-bit, m <= 64, k a multiple of 1024; `packed` = lmhead_pack of the (n, k) weight -> fp32 partial products
+    (k / 1024, m, n), one per 1024-wide slice of k, for rmsnorm_splitk or splitk_sum to add up."""
+    _dev(x, packed, out)
+    _need(x.dim() == 2 and x.stride(1) == 1 and x.dtype in H16 and packed.dtype == x.dtype and packed.is_contiguous(), "linear_stream: x / packed layout")
+    m, k = x.shape
+    _need(0 < m <= lmhead_rows_per_pass() and k % 1024 == 0, "linear_stream: at most 64 rows, k a multiple of 1024")
+    _need(packed.numel() == ((n + 15) // 16) * 16 * k, "linear_stream: packed weight size")
+    s = k // 1024
+    if out is None:
+        out = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
+    else:
+        _need(out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (s, m, n), "linear_stream: out")
+    lib = _lib.load()
+    _lib.check(_fn(lib, "nvx_linear_stream", x.dtype)(_ptr(packed), n, k, _ptr(x), x.stride(0), m, _ptr(out), _stream()), "nvx_linear_stream")
+    return out
+
+
+def lmhead_rows_per_pass() -> int:
+    return int(_lib.load().nvx_lmhead_rows_per_pass())
+
+
+def splitk_sum(partials, dtype, silu_mul: bool = False):
+    """(splits, rows, n) fp32 -> (rows, n) in `dtype`, or SiluAndMul of the summed [gate | up] projection, (rows, n / 2)."""
+    _dev(partials)
+    _need(partials.dim() == 3 and partials.dtype == torch.float32 and partials.is_contiguous() and dtype in H16, "splitk_sum: partials")
+    s, rows, n = partials.shape
+    y = torch.empty((rows, n // 2 if silu_mul else n), dtype=dtype, device=partials.device)
+    lib = _lib.load()
+    _lib.check(_fn(lib, "nvx_splitk_sum", dtype)(_ptr(partials), s, rows, n, int(silu_mul), _ptr(y), _stream()), "nvx_splitk_sum")
+    return y
+
+
 def sample_pick(winners, out=None):
     """Token ids from the ranks' keys: winners (n_sets, B) int64 (bit patterns of the 64-bit keys) -> (B,) int64."""
     _dev(winners)

@@ -26,6 +26,8 @@ _DEFS = {
     "sample_shard": "(Tensor logits, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset) -> Tensor",
     "sample_pick": "(Tensor winners) -> Tensor",
     "lmhead_pack": "(Tensor weight) -> Tensor",
+    "linear_stream": "(Tensor x, Tensor packed, int n) -> Tensor",
+    "splitk_sum": "(Tensor partials, bool half, bool silu_mul) -> Tensor",
     "lmhead_sample": "(Tensor packed, int n_rows, Tensor x, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset, "
                      "bool keys) -> Tensor",
     "qknorm_rope_store": "(Tensor qkv, Tensor positions, Tensor cos_sin, Tensor q_weight, Tensor k_weight, float eps, Tensor slots, "
@@ -97,6 +99,14 @@ def _sample_shard(logits, temperatures, vocab_offset, vocab, seed, offset):
 
 def _sample_pick(winners):
     return ops.sample_pick(winners)
+
+
+def _linear_stream(x, packed, n):
+    return ops.linear_stream(x, packed, n)
+
+
+def _splitk_sum(partials, half, silu_mul):
+    return ops.splitk_sum(partials, torch.float16 if half else torch.bfloat16, silu_mul)
 
 
 def _lmhead_pack(weight):

@@ -115,3 +115,35 @@ def test_limits_are_refused_on_the_host(ops):
         ops.lmhead_sample(ops.lmhead_pack(torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV)), 64,
                           torch.zeros(4, 512, dtype=torch.bfloat16, device=DEV), t[:4], 0, 64, 1, 1)
     assert ops.lmhead_max_rows() == 1024
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (29, 6144, 4096), (64, 1024, 12288), (17, 1000, 1024), (33, 24576, 4096)])
+def test_streamed_projection_and_its_consumers(ops, m, n, k):
+    """nvx_linear_stream: per 1024-wide slice of k, fp32 products of the same 16-bit operands; summed by nvx_splitk_sum
+    (plain and SiluAndMul) and by nvx_rmsnorm_splitk exactly as the K-split skinny projection's partials are."""
+    from oracle.layers_oracle import rmsnorm_oracle, silu_mul_oracle
+
+    gen = torch.Generator().manual_seed(m + n)
+    dt = torch.bfloat16
+    w = (torch.randn(n, k, generator=gen) * k ** -0.5).to(dt).to(DEV)
+    x = torch.randn(m, k, generator=gen).to(dt).to(DEV)
+    part = ops.linear_stream(x, ops.lmhead_pack(w), n)
+    assert part.shape == (k // 1024, m, n)
+    for s in range(k // 1024):
+        ref = x[:, s * 1024:(s + 1) * 1024].float() @ w[:, s * 1024:(s + 1) * 1024].float().t()
+        assert bool(((part[s] - ref).abs() <= ref.abs() * 1e-5 + 2e-5).all()), (s, float((part[s] - ref).abs().max()))
+    full = x.float() @ w.float().t()
+    y = ops.splitk_sum(part, dt)
+    assert y.dtype == dt and bool(((y.float() - full).abs() <= full.abs() * 2.0 ** -8 + 1e-5).all())
+    if n % 8 == 0:
+        act = ops.splitk_sum(part, dt, silu_mul=True)
+        want = silu_mul_oracle(y.cpu())       # the oracle on the very sum the kernel rounded
+        ulp = (act.cpu().view(torch.int16).int() - want.view(torch.int16).int()).abs().max().item()
+        assert act.shape == (m, n // 2) and ulp <= 2, ulp
+    nw = (1 + 0.1 * torch.randn(n, generator=gen)).to(dt).to(DEV)
+    res = torch.randn(m, n, generator=gen).to(dt).to(DEV)
+    if n % 4 == 0 and n <= 8192:
+        yn, ro = ops.rmsnorm_splitk(part, nw, 1e-6, residual=res)
+        yr, rr = rmsnorm_oracle(y.cpu(), nw.cpu(), 1e-6, res.cpu())
+        assert torch.equal(ro.cpu().view(torch.int16), rr.view(torch.int16))
+        assert (yn.cpu().view(torch.int16).int() - yr.view(torch.int16).int()).abs().max().item() <= 1

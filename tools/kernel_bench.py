@@ -265,6 +265,45 @@ def cmd_lmhead(args):
                           "linear_plus_sample_us": round(tt * 1e6, 1), "linear_alone_us": round(tg * 1e6, 1)}))
 
 
+def cmd_stream(args):
+    """Decode-step projections of Qwen3-8B (one GPU): the streamed projection + its consumer against torch (hipBLASLt)."""
+    import torch.nn.functional as F
+    shapes = [("qkv", 6144, 4096, "sum"), ("o", 4096, 4096, "norm"), ("gate_up+silu", 24576, 4096, "silu"), ("down", 4096, 12288, "norm")]
+    copies = 3
+    for m in (1, 8, 16, 29, 48, 64):
+        for name, n, k, consumer in shapes:
+            ws = [(torch.randn(n, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(copies)]
+            packed = [ops.lmhead_pack(w) for w in ws]
+            x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+            nw = torch.ones(n, device=DEV, dtype=torch.bfloat16)
+            res = torch.randn(m, n, device=DEV).to(torch.bfloat16)
+            part = torch.empty(k // 1024, m, n, dtype=torch.float32, device=DEV)
+            i = [0]
+
+            def ours():
+                i[0] += 1
+                ops.linear_stream(x, packed[i[0] % copies], n, out=part)
+                if consumer == "sum":
+                    ops.splitk_sum(part, torch.bfloat16)
+                elif consumer == "silu":
+                    ops.splitk_sum(part, torch.bfloat16, silu_mul=True)
+                else:
+                    ops.rmsnorm_splitk(part, nw, 1e-6, residual=res)
+
+            def lib():
+                i[0] += 1
+                y = F.linear(x, ws[i[0] % copies])
+                if consumer == "silu":
+                    ops.silu_mul(y)
+                elif consumer == "norm":
+                    ops.rmsnorm(y, nw, 1e-6, res)
+
+            t_ours, t_lib = timed(ours, args.reps), timed(lib, args.reps)
+            print(json.dumps({"kernel": "linear_stream+consumer", "layer": name, "M": m, "N": n, "K": k, "us": round(t_ours * 1e6, 2),
+                              "hipblaslt_path_us": round(t_lib * 1e6, 2), "weight_GBps": round(n * k * 2 / t_ours / 1e9)}))
+            del ws, packed
+
+
 def cmd_linear(args):
     """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
     import torch.nn.functional as F
@@ -296,7 +335,7 @@ def cmd_linear(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead"])
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead", "stream"])
     ap.add_argument("--every", type=int, default=8)
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
@@ -306,4 +345,4 @@ if __name__ == "__main__":
     ap.add_argument("--uniform-len", type=int, default=0)
     ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
-    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear, "lmhead": cmd_lmhead}[a.cmd](a)
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear, "lmhead": cmd_lmhead, "stream": cmd_stream}[a.cmd](a)
