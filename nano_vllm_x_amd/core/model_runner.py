@@ -102,6 +102,7 @@ class ModelRunner:
                 self.model.load_weights(_iter_safetensors(files))
             else:
                 self.model.init_random(self.seed)
+        self.model.pack_decode_weights()
         self.sampler = Sampler(seed=self.seed)
         # Decode-sized steps whose rows have no sampling filter take the LM head and the draw in ONE pass over the weight
         # (ops.lmhead_sample): the tiled copy of this rank's LM-head rows it streams is made here, once.  NVX_LMHEAD_FUSED=0

@@ -104,7 +104,13 @@ def linear_fp32(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return F.linear(x.float(), weight.float()).to(x.dtype)
 
 
-def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Tensor:
+# The streamed projection (ops.linear_stream) takes the gate/up weight of a decode step when it is at least this large and
+# the batch at most this tall; NVX_LINEAR_STREAM=0 keeps the library projection.
+STREAM_MIN_WEIGHT_BYTES = 128 << 20
+STREAM_GATEUP_MAX_ROWS = 32
+
+
+def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Projection of a decode batch.  Returns bf16 (rows, n) -- or, for the row-parallel projections
     ("o", "down") on a single rank, fp32 partial products (splits, rows, n) that the RMSNorm which
     follows sums (under tensor parallelism they stay 16-bit: the sum over ranks comes first);
@@ -131,6 +137,11 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str) -> torch.Ten
     if kind == "gate_up":
         if fits and (n // 2) % 16 == 0:
             return ops.linear_decode(x, weight, mode=1)
+        if packed is not None and rows <= STREAM_GATEUP_MAX_ROWS and x.stride(1) == 1:
+            # a weight of hundreds of MB: streamed once with the rows resident on every CU, SiluAndMul in the kernel that sums
+            # the K-slices' partials (Qwen3-8B, us per layer: 40 / 44 / 49 against 47 / 50 / 52 for the library projection +
+            # SiluAndMul at 1 / 16 / 29 rows; level from 48 rows on; tools/kernel_bench.py stream)
+            return ops.splitk_sum(ops.linear_stream(x, packed, n), x.dtype, silu_mul=True)
         return ops.silu_mul(F.linear(x, weight))
     if fits and n % 16 == 0:
         return ops.linear_decode(x, weight, mode=0)
@@ -202,10 +213,17 @@ class Qwen3MLP(nn.Module):
         self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * inter, bias=False)
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
         self.act_fn = SiluAndMul()
+        self.gate_up_packed: Optional[torch.Tensor] = None    # tiled copy for ops.linear_stream (large weights only)
+
+    def pack_decode_weights(self):
+        w = self.gate_up_proj.weight
+        if (os.environ.get("NVX_LINEAR_STREAM", "1") != "0" and w.is_cuda and w.dtype in (torch.bfloat16, torch.float16)
+                and w.numel() * w.element_size() >= STREAM_MIN_WEIGHT_BYTES and w.shape[1] % 1024 == 0 and w.shape[0] % 8 == 0):
+            self.gate_up_packed = ops.lmhead_pack(w.detach())
 
     def forward(self, x, decode: bool = False):
         if decode:
-            out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up"), self.down_proj.weight, "down")
+            out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up", self.gate_up_packed), self.down_proj.weight, "down")
             return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
         if FP32_LINEAR:
             return tpd.tp_reduce_later(linear_fp32(self.act_fn(linear_fp32(x, self.gate_up_proj.weight)), self.down_proj.weight))
@@ -382,6 +400,11 @@ class Qwen3ForCausalLM(nn.Module):
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         return self.model(input_ids, positions, self.fused)
+
+    def pack_decode_weights(self):
+        """Call once the weights are in place: tiled copies of the weights that decode steps stream (large gate/up projections)."""
+        for layer in self.model.local_layers():
+            layer.mlp.pack_decode_weights()
 
     def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
         if FP32_LINEAR:
