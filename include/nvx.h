@@ -111,8 +111,9 @@ int nvx_silu_mul(const void* x, void* y, int64_t rows, int64_t d, nvx_stream_t s
  *         partial products, to be summed by nvx_rmsnorm_splitk.  nvx_linear_decode_splits(n, k)
  *         proposes k_splits.
  * fp32 accumulation on MFMA; k / k_splits must be 512, 768 or 1024 (nvx_linear_decode_splits
- * returns 0 when no split of k gives one of them: use a library GEMM then); output width a
- * multiple of 16. */
+ * returns 0 when no split of k gives one of them: use a library GEMM then); mode 0 also takes
+ * k = 256 and k = 1536 whole (a tensor-parallel rank's share of K in the row-parallel projections,
+ * nanovllmx/layers/linear.py:266-280); output width a multiple of 16. */
 int nvx_linear_decode_splits(int64_t n, int64_t k);
 int nvx_linear_decode(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t m,
                       int64_t n, int64_t k, int mode, int k_splits, nvx_stream_t stream);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linear_decode_kernel(
     static_assert(!(WIDE && MODE == 1), "the gate/up mode already owns 32 rows of W");
     constexpr int HALVES = (MODE == 1 || WIDE) ? 2 : 1;
     constexpr int STEPS = KC / 32;               // MFMA k-steps per tile
-    constexpr int GPT = STAGED ? STEPS / 8 : ((MODE == 1 && KC == 1024) ? 4 : 2);   // groups per tile
+    constexpr int GPT = STAGED ? STEPS / 8 : ((MODE == 1 && KC == 1024) ? 4 : (KC > 1024 ? KC / 512 : 2));   // groups per tile
     constexpr int GROUP = STEPS / GPT;           // k-steps per group (direct: half a tile in flight; staged: 8 = 256 k)
     constexpr int PIECES_ROW = KC / 8;           // 16-byte pieces per W row
     constexpr int PIECES_HALF = 16 * PIECES_ROW;
@@ -310,6 +310,9 @@ static int lin_msplit() { static int v = -1; if (v < 0) { v = lin_env_int("NVX_L
 static int lin_gateup_wide_min_rows() { static int v = -1; if (v < 0) v = lin_env_int("NVX_LIN_GATEUP_WIDE_MIN", 112); return v; }
 
 static bool lin_chunk_ok(int64_t kc) { return kc == 512 || kc == 768 || kc == 1024; }
+// whole-K sizes built for mode 0 only: a tensor-parallel rank's share of K in the row-parallel projections
+// (2048 / 8 and 3072 / 2 for the 0.6B geometry), whose 16-bit result goes to the all-reduce
+static bool lin_whole_k_ok(int64_t k) { return k == 256 || k == 1536; }
 
 #ifndef NVX_F16   // independent of the 16-bit format: defined by the bfloat16 build only
 extern "C" int nvx_linear_decode_splits(int64_t n, int64_t k) {
@@ -330,8 +333,9 @@ extern "C" int NVX_ENTRY(nvx_linear_decode)(const void* x, int64_t x_row_stride,
     NVX_REQUIRE(m > 0 && m <= 256, NVX_EUNSUPPORTED, "nvx_linear_decode: 1..256 rows (got %lld); larger batches are a library GEMM", (long long)m);
     NVX_REQUIRE(mode >= 0 && mode <= 2, NVX_EINVAL, "nvx_linear_decode: mode must be 0, 1 or 2");
     NVX_REQUIRE(k_splits >= 1 && (mode == 2 || k_splits == 1), NVX_EINVAL, "nvx_linear_decode: only mode 2 (fp32 partials) may split K");
-    NVX_REQUIRE(k > 0 && k % k_splits == 0 && lin_chunk_ok(k / k_splits), NVX_EUNSUPPORTED,
-                "nvx_linear_decode: K / k_splits must be 512, 768 or 1024 (got %lld / %d)", (long long)k, k_splits);
+    const bool whole_k = mode == 0 && k_splits == 1 && lin_whole_k_ok(k);
+    NVX_REQUIRE(k > 0 && k % k_splits == 0 && (lin_chunk_ok(k / k_splits) || whole_k), NVX_EUNSUPPORTED,
+                "nvx_linear_decode: K / k_splits must be 512, 768 or 1024, or K 256 or 1536 in mode 0 (got %lld / %d)", (long long)k, k_splits);
     const int64_t n_out = mode == 1 ? n / 2 : n;
     NVX_REQUIRE(n > 0 && n_out % 16 == 0 && (mode != 1 || n % 2 == 0), NVX_EUNSUPPORTED, "nvx_linear_decode: output width must be a multiple of 16");
     NVX_REQUIRE(x_row_stride >= k && x_row_stride % 8 == 0, NVX_EINVAL, "nvx_linear_decode: bad x row stride");
@@ -339,7 +343,7 @@ extern "C" int NVX_ENTRY(nvx_linear_decode)(const void* x, int64_t x_row_stride,
     const int kc = (int)(k / k_splits);
     hipStream_t st = (hipStream_t)stream;
     const bool staged = m > lin_staged_min_rows();
-    const bool wide = mode != 1 && staged && lin_wide_min_rows() > 0 && m >= lin_wide_min_rows() && n_out % 32 == 0;
+    const bool wide = mode != 1 && staged && !whole_k && lin_wide_min_rows() > 0 && m >= lin_wide_min_rows() && n_out % 32 == 0;
     const int msplit = wide && ((n_out / 32) * k_splits) % 8 == 0 ? lin_msplit() : 1;
     const dim3 grid((unsigned)(n_out / (wide ? 32 : 16)), (unsigned)k_splits, (unsigned)msplit);
 #define NVX_LIN(MODE, KC, ST, WD) hipLaunchKernelGGL((linear_decode_kernel<MODE, KC, ST, WD>), grid, dim3(LIN_THREADS), 0, st, (const uint16_t*)x, \
@@ -347,6 +351,11 @@ extern "C" int NVX_ENTRY(nvx_linear_decode)(const void* x, int64_t x_row_stride,
 #define NVX_LIN_KC(MODE, ST, WD) do { if (kc == 512) NVX_LIN(MODE, 512, ST, WD); else if (kc == 768) NVX_LIN(MODE, 768, ST, WD); else NVX_LIN(MODE, 1024, ST, WD); } while (0)
 #define NVX_LIN_ST(MODE) do { if (staged) NVX_LIN_KC(MODE, true, false); else NVX_LIN_KC(MODE, false, false); } while (0)
     const int64_t tiles = (m + 15) / 16;
+    if (whole_k) {
+        if (kc == 256) { if (staged) NVX_LIN(0, 256, true, false); else NVX_LIN(0, 256, false, false); }
+        else { if (staged) NVX_LIN(0, 1536, true, false); else NVX_LIN(0, 1536, false, false); }
+        return nvx_check_launch("nvx_linear_decode");
+    }
     if (mode == 1 && staged && lin_gateup_wide_min_rows() > 0 && m >= lin_gateup_wide_min_rows() && kc == 1024 && n_out % 32 == 0 &&
         (n_out / 32) % 8 == 0 && lin_msplit() == 2 && tiles <= 2 * LIN_WAVES) {
         hipLaunchKernelGGL((linear_gateup_wide_kernel<1024>), dim3((unsigned)(n_out / 32), 1, 2), dim3(LIN_THREADS), 0, st,

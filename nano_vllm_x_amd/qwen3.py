@@ -125,8 +125,8 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Opti
     if kind in ("o", "down"):
         if tpd.collectives_active():
             # a tensor-parallel rank hands its partial result to the all-reduce in the 16-bit format (linear.py:277-278);
-            # its share of K is 1/tp of the full one, which the skinny kernel takes whole where it is 512, 768 or 1024
-            if use and k in (512, 768, 1024) and n % 16 == 0:
+            # its share of K is 1/tp of the full one, which the skinny kernel takes whole where it is one of these
+            if use and k in (256, 512, 768, 1024, 1536) and n % 16 == 0:
                 return ops.linear_decode(x, weight, mode=0)
             return F.linear(x, weight)
         splits = ops.linear_decode_splits(n, k) if use and n % 16 == 0 else 0

@@ -308,6 +308,10 @@ def cmd_linear(args):
     """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
     import torch.nn.functional as F
     shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up+silu", 6144, 1024, 1), ("down", 1024, 3072, 2)]
+    if args.tp > 1:     # one rank's share: column-parallel N / tp, row-parallel K / tp with a 16-bit result for the all-reduce
+        tp = args.tp
+        shapes = [("qkv", 4096 // tp, 1024, 0), ("o", 1024, 2048 // tp, 0), ("gate_up+silu", 6144 // tp, 1024, 1), ("down", 1024, 3072 // tp, 0)]
+        shapes = [sh for sh in shapes if sh[2] in (256, 512, 768, 1024, 1536)]
     layers = 28
     for m in ((int(os.environ["NVX_BENCH_M"]),) if os.environ.get("NVX_BENCH_M") else (1, 8, 29, 64, 123, 256)):
         for name, n, k, mode in shapes:
@@ -337,6 +341,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead", "stream"])
     ap.add_argument("--every", type=int, default=8)
+    ap.add_argument("--tp", type=int, default=1, help="linear: the shapes of one rank of a tensor-parallel job")
     ap.add_argument("--reps", type=int, default=28)
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--hkv1", action="store_true")
