@@ -55,6 +55,19 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quarter = lane >> 4, l16 = lane & 15;
 
+    // The wave's current tile as A operands: 32 steps x 16 bytes per lane.  Each register is refilled with the NEXT
+    // tile's piece right after the products that read it, so a whole tile (32 KB per wave) is always in flight and the
+    // draw over the finished tile runs under it.  The first tile is requested before anything else: its trip to HBM
+    // and the rows' trip to L2 below then overlap instead of following each other.
+    const int stride_tiles = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    nvx_u32x4 a[KS];
+    if (tile < n_tiles) {
+        const nvx_u32x4* wt = wp + (int64_t)tile * KS * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[kk] = lmh_stream16(wt + kk * 64);
+    }
+
     // the batch's rows -> LDS, in operand order (coalesced 16-byte reads along k; rows past the batch are zeros)
     for (int i = tid; i < MT * 16 * (K / 8); i += 256) {
         const int m = i / (K / 8), c = i % (K / 8);
@@ -76,19 +89,8 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
         best[mt] = -INFINITY; besti[mt] = 0x7fffffff;
     }
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
-    const int stride_tiles = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
-
-    // The wave's current tile as A operands: 32 steps x 16 bytes per lane.  Each register is refilled with the NEXT
-    // tile's piece right after the products that read it, so a whole tile (32 KB per wave) is always in flight and the
-    // draw over the finished tile runs under it.  sched_barrier keeps the compiler from hoisting every LDS read of a
-    // tile to the top (it would need 128 registers per 16 batch rows).
-    nvx_u32x4 a[KS];
-    if (tile < n_tiles) {
-        const nvx_u32x4* wt = wp + (int64_t)tile * KS * 64 + lane;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a[kk] = lmh_stream16(wt + kk * 64);
-    }
+    // sched_barrier in the loop keeps the compiler from hoisting every LDS read of a tile to the top (it would need 128
+    // registers per 16 batch rows)
     while (tile < n_tiles) {
         const int next = tile + stride_tiles;
         // (past the end: the same tile again, an L2 hit that is never used -- keeps the loop free of branches)
@@ -104,11 +106,7 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
                 for (int mt = 0; mt < MT; ++mt) bn[mt] = xs[(mt * KS + kk + 1) * 64 + lane];
             }
 #pragma unroll
-#ifndef LMH_NO_MFMA
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_16x16x32_h16(a[kk], b[mt], acc[mt]);
-#else
-            for (int mt = 0; mt < MT; ++mt) acc[mt][0] += __uint_as_float(a[kk][0] ^ b[mt][1]);
-#endif
             a[kk] = lmh_stream16(wn + kk * 64);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) b[mt] = bn[mt];
@@ -128,18 +126,12 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
                         make_uint2(pack_h16x2(lg[0], lg[1]), pack_h16x2(lg[2], lg[3]));
                 }
                 uint4 r = make_uint4(0, 0, 0, 0);
-#ifndef LMH_NO_EPI
                 if (!greedy[mt]) r = philox4x32_10(make_uint4((uint32_t)((tok0 + base) >> 2), (uint32_t)(row0 + m), (uint32_t)offset, (uint32_t)(offset >> 32)), key);
-#endif
                 const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (tok0 + base + j < tok_end) {
-#ifndef LMH_NO_EPI
                         const float v = lg[j] * inv_t[mt] + (greedy[mt] ? 0.0f : gumbel_from_bits(rr[j]));
-#else
-                        const float v = lg[j] * inv_t[mt] + __uint_as_float(rr[j]);
-#endif
                         if (v > best[mt]) { best[mt] = v; besti[mt] = tok0 + base + j; }
                     }
                 }
@@ -188,6 +180,19 @@ __global__ __launch_bounds__(256, 1) void linear_stream_kernel(
     const int quarter = lane >> 4, l16 = lane & 15;
     const int slice = blockIdx.x % n_slices, group = blockIdx.x / n_slices, n_groups = gridDim.x / n_slices;
 
+    const int64_t tile_pitch = (int64_t)n_slices * KS * 64;            // 16-byte pieces per tile of 16 rows over all of k
+    const nvx_u32x4* base = wp + (int64_t)slice * KS * 64 + lane;
+    const int stride_tiles = n_groups * 4;
+    int tile = group * 4 + wave;
+    float* out = partials + (int64_t)slice * m_rows * n_cols;
+
+    // the first tile is requested before the rows are staged: the two trips overlap
+    nvx_u32x4 a[KS];
+    if (tile < n_tiles) {
+        const nvx_u32x4* wt = base + (int64_t)tile * tile_pitch;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[kk] = lmh_stream16(wt + kk * 64);
+    }
     for (int i = tid; i < MT * 16 * 128; i += 256) {
         const int m = i >> 7, c = i & 127;
         nvx_u32x4 v = {0u, 0u, 0u, 0u};
@@ -195,20 +200,6 @@ __global__ __launch_bounds__(256, 1) void linear_stream_kernel(
         xs[((m >> 4) * KS + (c >> 2)) * 64 + (c & 3) * 16 + (m & 15)] = v;
     }
     __syncthreads();
-    if (group >= n_groups) return;   // (workgroups beyond a whole number of slice groups)
-
-    const int64_t tile_pitch = (int64_t)n_slices * KS * 64;            // 16-byte pieces per tile of 16 rows over all of k
-    const nvx_u32x4* base = wp + (int64_t)slice * KS * 64 + lane;
-    const int stride_tiles = n_groups * 4;
-    int tile = group * 4 + wave;
-    float* out = partials + (int64_t)slice * m_rows * n_cols;
-
-    nvx_u32x4 a[KS];
-    if (tile < n_tiles) {
-        const nvx_u32x4* wt = base + (int64_t)tile * tile_pitch;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a[kk] = lmh_stream16(wt + kk * 64);
-    }
     while (tile < n_tiles) {
         const int next = tile + stride_tiles;
         const nvx_u32x4* wn = base + (int64_t)(next < n_tiles ? next : tile) * tile_pitch;

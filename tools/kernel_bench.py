@@ -269,9 +269,11 @@ def cmd_stream(args):
     """Decode-step projections of Qwen3-8B (one GPU): the streamed projection + its consumer against torch (hipBLASLt)."""
     import torch.nn.functional as F
     shapes = [("qkv", 6144, 4096, "sum"), ("o", 4096, 4096, "norm"), ("gate_up+silu", 24576, 4096, "silu"), ("down", 4096, 12288, "norm")]
-    copies = 3
     for m in (1, 8, 16, 29, 48, 64):
         for name, n, k, consumer in shapes:
+            # enough copies that no call finds its weight in the 256 MB memory-side cache (in the model the other layers'
+            # weights pass through between two uses of one)
+            copies = max(3, -(-(768 << 20) // (n * k * 2)))
             ws = [(torch.randn(n, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(copies)]
             packed = [ops.lmhead_pack(w) for w in ws]
             x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
