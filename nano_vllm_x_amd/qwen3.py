@@ -107,7 +107,7 @@ def linear_fp32(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
 # The streamed projection (ops.linear_stream) takes the gate/up weight of a decode step when it is at least this large and
 # the batch at most this tall; NVX_LINEAR_STREAM=0 keeps the library projection.
 STREAM_MIN_WEIGHT_BYTES = 128 << 20
-STREAM_GATEUP_MAX_ROWS = 32
+STREAM_GATEUP_MAX_ROWS = 16
 
 
 def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -139,8 +139,8 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Opti
             return ops.linear_decode(x, weight, mode=1)
         if packed is not None and rows <= STREAM_GATEUP_MAX_ROWS and x.stride(1) == 1:
             # a weight of hundreds of MB: streamed once with the rows resident on every CU, SiluAndMul in the kernel that sums
-            # the K-slices' partials (Qwen3-8B, us per layer: 40 / 44 / 49 against 47 / 50 / 52 for the library projection +
-            # SiluAndMul at 1 / 16 / 29 rows; level from 48 rows on; tools/kernel_bench.py stream)
+            # the K-slices' partials (Qwen3-8B, us per layer with the weight coming from HBM: 41 / 44 against 47 / 46 for the
+            # library projection + SiluAndMul at 1 / 16 rows, 51 against 48 at 29 rows; tools/kernel_bench.py stream)
             return ops.splitk_sum(ops.linear_stream(x, packed, n), x.dtype, silu_mul=True)
         return ops.silu_mul(F.linear(x, weight))
     if fits and n % 16 == 0:
