@@ -411,6 +411,12 @@ class ModelRunner:
         assert self.graph is not None
         bt = self.block_table
         sizes = decode_batch_ladder(self.max_bs)
+        if self.tp_size > 1:
+            # a batch whose all-reduce goes through a library that cannot be captured (gloo, in rehearsals of several ranks on
+            # one device) keeps eager steps; the sizes below it are captured as usual
+            sizes = [bs for bs in sizes if tpd.decode_graph_capturable(bs)]
+            if not sizes:
+                raise RuntimeError("the all-reduce of this group cannot be captured at any decode batch size")
         hidden_out = torch.zeros((self.max_bs, self.hf_config.hidden_size), dtype=self.dtype, device=self.device)
         self.graph.set_input_buffer("step", bt.step_dev)
         self.graph.set_input_buffer("input_ids", bt.input_ids)

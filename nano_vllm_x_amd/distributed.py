@@ -135,6 +135,14 @@ def _via_host(x: torch.Tensor) -> bool:
     return x.is_cuda and dist.get_backend() == "gloo"
 
 
+def decode_graph_capturable(rows: int) -> bool:
+    """Can the all-reduces of a decode step of `rows` rows be recorded into a graph?  RCCL's can; gloo moves tensors
+    through host memory, so under gloo only the sizes the direct-peer exchange takes."""
+    if not collectives_active() or not dist.is_initialized() or dist.get_backend(_TP_GROUP) != "gloo":
+        return True
+    return _PEER is not None and rows <= _PEER.max_rows
+
+
 def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) -> bool:
     """Set up the direct-peer all-reduce for this stage's TP group (every rank of the group calls this at the same
     point): allocate the landing buffer, exchange the inter-process handles through the process group, map the
@@ -150,11 +158,15 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
         return _PEER is not None
     tp, rank = max(_TP_SIZE, 1), _TP_RANK
     group, err = None, None
-    if tp > 1 and ranks_on_my_device(device) > 1:
-        # Ranks rehearsed on ONE device: a peer's exchange kernel waits for this rank with a workgroup on every CU, so a
-        # kernel of this rank that needs a whole SIMD's registers (the 64-row gate/up projection, used from 112 rows)
-        # could never be placed and every wait would run into its time-out.  Keep that kernel off (the library reads the
-        # variable at its first projection, which comes later).  Ranks on GPUs of their own never share a CU.
+    sharing = ranks_on_my_device(device) if tp > 1 else 1
+    if sharing > 1:
+        # Ranks rehearsed on ONE device: a peer's exchange kernel waits for this rank with a workgroup (four waves of
+        # ~80 registers) per row, spread over the CUs.  A kernel of this rank that needs most of a SIMD's registers
+        # cannot be placed beside the waiting waves of several peers, and a rank that cannot run is a rank everybody
+        # waits for until the time-out.  So the whole-SIMD gate/up projection (used from 112 rows) stays off (the
+        # library reads the variable at its first projection, which comes later), and below the exchange is kept to so
+        # few rows that all peers together put at most one waiting wave on a SIMD; taller batches take the library
+        # all-reduce.  Ranks on GPUs of their own never share a CU.
         os.environ.setdefault("NVX_LIN_GATEUP_WIDE_MIN", "1000000")
     # one routing limit for the whole group (a rank that read another NVX_PEER_MAX_PUSH_BYTES would send a tensor through
     # the library while its peers wait for it in the exchange kernel): the smallest any rank holds
@@ -165,6 +177,8 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
         push = min(pushes)
     # the landing buffer is sized for the rows that will ever take this path: the decode batch, capped by the limit above
     rows_cap = min(max(max_rows, 1), 512, ops.PeerGroup.rows_within_push_cap(tp, hidden, push))
+    if sharing > 1:
+        rows_cap = min(rows_cap, max(8, 128 // (sharing - 1)))
     try:
         if tp > 8:
             raise RuntimeError("more than 8 ranks")

@@ -78,6 +78,8 @@ def _case_collectives(rank: int):
     assert tpd.tp_all_gather_rows(keys).tolist() == [[1, 2, 3], [11, 12, 13]]
     # without a GPU there is no direct-peer exchange: it reports so, and a row-parallel output is reduced at once
     assert tpd.init_peer_allreduce(8, 64, torch.bfloat16, "cpu") is False and not tpd.peer_allreduce_active()
+    # gloo moves tensors through host memory: without the direct-peer exchange no decode size of this group can be recorded
+    assert tpd.decode_graph_capturable(1) is False and tpd.ranks_on_my_device("cpu") == 1
     y = tpd.tp_reduce_later(torch.full((2, 64), float(rank + 1)))
     assert isinstance(y, torch.Tensor) and torch.equal(y, torch.full((2, 64), 3.0))
     assert tpd.tp_finish_reduce(y) is y
