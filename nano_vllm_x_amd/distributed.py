@@ -159,6 +159,8 @@ def init_peer_allreduce(max_rows: int, hidden: int, dtype: torch.dtype, device) 
     tp, rank = max(_TP_SIZE, 1), _TP_RANK
     group, err = None, None
     sharing = ranks_on_my_device(device) if tp > 1 else 1
+    if os.environ.get("NVX_PEER_SHARED_DEVICE") == "0":
+        sharing = 1            # size the group as on GPUs of their own although the ranks share one (tests of the sizing)
     if sharing > 1:
         # Ranks rehearsed on ONE device: a peer's exchange kernel waits for this rank with a workgroup (four waves of
         # ~80 registers) per row, spread over the CUs.  A kernel of this rank that needs most of a SIMD's registers

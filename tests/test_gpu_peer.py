@@ -243,7 +243,7 @@ def _routing_worker(rank, tp, port, q):
         if ok:
             cap = 4 * 1024 * 1024 // ((tp - 1) * HIDDEN * 4)
             facts["max_rows"], facts["cap"] = group.max_rows, cap
-            small = torch.full((29, HIDDEN), float(rank + 1), dtype=torch.bfloat16, device=dev)
+            small = torch.full((min(29, group.max_rows), HIDDEN), float(rank + 1), dtype=torch.bfloat16, device=dev)
             tall = torch.full((256, HIDDEN), float(rank + 1), dtype=torch.bfloat16, device=dev)
             a = tpd.tp_reduce_later(small)
             b = tpd.tp_reduce_later(tall)
@@ -260,12 +260,20 @@ def _routing_worker(rank, tp, port, q):
         q.put((rank, None, traceback.format_exc()))
 
 
-def test_the_group_comes_up_at_the_bench_configuration_and_routes_by_size():
+@pytest.mark.parametrize("as_on_own_gpus", [True, False])
+def test_the_group_comes_up_at_the_bench_configuration_and_routes_by_size(as_on_own_gpus, monkeypatch):
+    """Sized as for eight GPUs (NVX_PEER_SHARED_DEVICE=0: 146 rows fit the push limit), and as the eight ranks of a rehearsal
+    on this one GPU get it by themselves: 128 / 7 rows, so that the waiting waves of seven peers leave every SIMD room for
+    this rank's kernels."""
     tp = 8
+    if as_on_own_gpus:
+        monkeypatch.setenv("NVX_PEER_SHARED_DEVICE", "0")
+    else:
+        monkeypatch.delenv("NVX_PEER_SHARED_DEVICE", raising=False)
     results = _spawn(_routing_worker, tp)
     for r in range(tp):
         f = results[r]
         assert f["ok"] and f["state"].startswith("direct-peer"), f["state"]
-        assert f["max_rows"] == min(256, f["cap"]) == 146
+        assert f["cap"] == 146 and f["max_rows"] == (146 if as_on_own_gpus else 18)
         assert f["small_is_deferred"] and f["tall_is_reduced_now"] and f["small_sum_ok"] and f["accepts_not_prefers"]
         assert f["status"] == 0

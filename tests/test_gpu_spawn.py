@@ -42,7 +42,9 @@ print("RESULT " + json.dumps({"want": [n for _, n in reqs], "first": first, "sec
 
 
 def test_llm_with_two_ranks_from_a_plain_process():
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+    # a plain process: no launcher variables, and none of the switches other tests of this session may have left set
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK") and not k.startswith("NVX_")}
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=400)
     line = next((ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")), None)
     assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-3000:]
