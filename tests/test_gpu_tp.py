@@ -33,7 +33,8 @@ PROMPT_LENS = (5, 19, 33, 8)
 
 
 def _run_model(tp: int, rank: int, port: int, pp: int = 1, eager: bool = True, peer: str = "1"):
-    os.environ["NVX_PEER_AR"] = peer if tp > 1 else "0"
+    if tp > 1:      # (a child process of the test: nothing leaks; the one-rank reference runs inside the test process)
+        os.environ["NVX_PEER_AR"] = peer
     from nano_vllm_x_amd import distributed as tpd
     from nano_vllm_x_amd.core.common import ForwardBatch, ForwardMode, SamplingParams, Sequence
     from nano_vllm_x_amd.core.model_runner import ModelRunner
