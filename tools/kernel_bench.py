@@ -310,6 +310,8 @@ def cmd_linear(args):
     """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
     import torch.nn.functional as F
     shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up+silu", 6144, 1024, 1), ("down", 1024, 3072, 2)]
+    if os.environ.get("NVX_BENCH_SHAPES"):   # "name,n,k,mode;..." (mode 2 = K-split partials + the norm that sums them)
+        shapes = [(a, int(b), int(c), int(d)) for a, b, c, d in (x.split(",") for x in os.environ["NVX_BENCH_SHAPES"].split(";"))]
     if args.tp > 1:     # one rank's share: column-parallel N / tp, row-parallel K / tp with a 16-bit result for the all-reduce
         tp = args.tp
         shapes = [("qkv", 4096 // tp, 1024, 0), ("o", 1024, 2048 // tp, 0), ("gate_up+silu", 6144 // tp, 1024, 1), ("down", 1024, 3072 // tp, 0)]
@@ -324,14 +326,22 @@ def cmd_linear(args):
             out = torch.empty(shape, dtype=torch.float32 if mode == 2 else torch.bfloat16, device=DEV)
             i = [0]
 
+            with_norm = mode == 2 and os.environ.get("NVX_BENCH_WITH_NORM") == "1"
+            nw = torch.ones(n, device=DEV, dtype=torch.bfloat16)
+            res = torch.randn(m, n, device=DEV).to(torch.bfloat16)
+
             def ours():
                 ops.linear_decode(x, ws[i[0]], mode=mode, k_splits=s, out=out)
+                if with_norm:
+                    ops.rmsnorm_splitk(out, nw, 1e-6, residual=res)
                 i[0] = (i[0] + 1) % layers
 
             def lib():
                 y = F.linear(x, ws[i[0]])
                 if mode == 1:
                     ops.silu_mul(y)
+                if with_norm:
+                    ops.rmsnorm(y, nw, 1e-6, res)
                 i[0] = (i[0] + 1) % layers
 
             t_ours, t_lib = timed(ours, args.reps), timed(lib, args.reps)
