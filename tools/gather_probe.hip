@@ -55,6 +55,39 @@ __global__ __launch_bounds__(256, 4) void gather_a(const char* __restrict__ kc, 
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// mode A': as mode A, but every kv head has a pool of its own ([head][slot][256 B] instead of [slot][head][256 B]): with the
+// slots of a sequence in a row (a prompt's are), a workgroup then reads one contiguous run of 256-byte rows.
+template <int TPQ>
+__global__ __launch_bounds__(256, 4) void gather_a_headpools(const char* __restrict__ kc, const char* __restrict__ vc, const int* __restrict__ idx,
+                                                              int n_tokens, int chunk, size_t pool_bytes, unsigned* __restrict__ sink) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, piece = lane & 15;
+    const int n_units = ((n_tokens + chunk - 1) / chunk) * 8;
+    unsigned acc = 0;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int c = unit >> 3, head = unit & 7;
+        const int lo = c * chunk, n = min(chunk, n_tokens - lo);
+        const char* kb = kc + (size_t)head * pool_bytes + piece * 16;
+        const char* vb = vc + (size_t)head * pool_bytes + piece * 16;
+        constexpr int TILE = 4 * TPQ, STEP = 4 * TILE;
+        int slots[TPQ];
+#pragma unroll
+        for (int u = 0; u < TPQ; ++u) { const int t = wave * TILE + u * 4 + quarter; slots[u] = t < n ? idx[lo + t] : 0; }
+        for (int tile = wave * TILE; tile < n; tile += STEP) {
+            u32x4 k[TPQ], v[TPQ];
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) {
+                const unsigned long long off = (unsigned long long)(unsigned)slots[u] * 256ull;
+                k[u] = ntload(kb + off); v[u] = ntload(vb + off);
+            }
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) { const int t = tile + STEP + u * 4 + quarter; slots[u] = t < n ? idx[lo + t] : 0; }
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) acc ^= k[u].x ^ k[u].y ^ k[u].z ^ k[u].w ^ v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // mode B: unit = chunk of `chunk` tokens, all heads; wave w: heads 4 (w & 1) .. +3 (1 KB of the row), tokens of parity w >> 1
 template <int TPQ>
 __global__ __launch_bounds__(256, 4) void gather_b(const char* __restrict__ kc, const char* __restrict__ vc, const int* __restrict__ idx,
@@ -171,6 +204,30 @@ int main(int argc, char** argv) {
         RUN_C(1, 16) RUN_C(2, 16) RUN_C(1, 32) RUN_C(2, 32) RUN_C(4, 32) RUN_C(2, 64) RUN_C(4, 64)
         RUN_A(2) RUN_A(4) RUN_A(8)
         RUN_B(2, 16) RUN_B(4, 16) RUN_B(8, 16) RUN_B(2, 32) RUN_B(4, 32) RUN_B(8, 32) RUN_B(4, 64) RUN_B(8, 64)
+    }
+    // How the slots of a sequence lie matters as much as how a row is cut.  Three slot lists of the same length: a random
+    // permutation (above), runs of 558 consecutive slots (prompts as the allocator hands them out) starting at random
+    // places, and those runs with every fourth token replaced by a far slot (tokens appended one per decode step).
+    {
+        std::vector<int> runs(n_slots), mixed(n_slots);
+        std::uniform_int_distribution<int> start(0, n_slots - 600);
+        for (int i = 0; i < n_slots; i += 558) {
+            const int s0 = start(rng);
+            for (int j = 0; j < 558 && i + j < n_slots; ++j) { runs[i + j] = s0 + j; mixed[i + j] = (j & 3) == 3 ? perm[i + j] : s0 + j; }
+        }
+        int *idx_runs, *idx_mixed;
+        CHECK(hipMalloc(&idx_runs, (size_t)n_slots * 4)); CHECK(hipMemcpy(idx_runs, runs.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice));
+        CHECK(hipMalloc(&idx_mixed, (size_t)n_slots * 4)); CHECK(hipMemcpy(idx_mixed, mixed.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice));
+        const size_t pool_bytes = (size_t)n_slots * 256;
+        struct { const char* what; const int* list; } lists[] = {{"random slots", idx}, {"runs of 558", idx_runs}, {"runs, every 4th far", idx_mixed}};
+        for (auto& l : lists) {
+            char name[160];
+            const int* base = l.list;
+            snprintf(name, sizeof name, "A  [slot][head] rows, %s, grid=2048", l.what);
+            timeit(name, [&](int r) { hipLaunchKernelGGL(gather_a<2>, dim3(2048), dim3(256), 0, 0, kc, vc, base + (size_t)(r % windows) * tokens, tokens, 128, sink); });
+            snprintf(name, sizeof name, "A' [head][slot] pools, %s, grid=2048", l.what);
+            timeit(name, [&](int r) { hipLaunchKernelGGL(gather_a_headpools<2>, dim3(2048), dim3(256), 0, 0, kc, vc, base + (size_t)(r % windows) * tokens, tokens, 128, pool_bytes, sink); });
+        }
     }
     timeit("stream read of the same bytes, grid=2048", [&](int r) {
         const int w = (int)std::max<size_t>(1, ((size_t)n_slots * 2048) / (size_t)bytes);
