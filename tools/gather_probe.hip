@@ -88,6 +88,41 @@ __global__ __launch_bounds__(256, 4) void gather_a_headpools(const char* __restr
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// mode A-rot: mode A, but the workgroup of head h walks its chunk starting `rot * h` tokens in (wrapping round), so that the
+// eight workgroups of a chunk -- launched side by side, one per XCD -- are not on the same 2 KB rows at the same time.
+template <int TPQ>
+__global__ __launch_bounds__(256, 4) void gather_a_rot(const char* __restrict__ kc, const char* __restrict__ vc, const int* __restrict__ idx,
+                                                        int n_tokens, int chunk, int rot, unsigned* __restrict__ sink) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, piece = lane & 15;
+    const int n_units = ((n_tokens + chunk - 1) / chunk) * 8;
+    unsigned acc = 0;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int c = unit >> 3, head = unit & 7;
+        const int lo = c * chunk, n = min(chunk, n_tokens - lo);
+        const int shift = (head * rot) % (n > 0 ? n : 1);
+        const char* kb = kc + head * 256 + piece * 16;
+        const char* vb = vc + head * 256 + piece * 16;
+        constexpr int TILE = 4 * TPQ, STEP = 4 * TILE;
+        auto at = [&](int t) { int r = t + shift; r = r >= n ? r - n : r; return idx[lo + r]; };
+        int slots[TPQ];
+#pragma unroll
+        for (int u = 0; u < TPQ; ++u) { const int t = wave * TILE + u * 4 + quarter; slots[u] = t < n ? at(t) : 0; }
+        for (int tile = wave * TILE; tile < n; tile += STEP) {
+            u32x4 k[TPQ], v[TPQ];
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) {
+                const unsigned long long off = (unsigned long long)(unsigned)slots[u] * 2048ull;
+                k[u] = ntload(kb + off); v[u] = ntload(vb + off);
+            }
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) { const int t = tile + STEP + u * 4 + quarter; slots[u] = t < n ? at(t) : 0; }
+#pragma unroll
+            for (int u = 0; u < TPQ; ++u) acc ^= k[u].x ^ k[u].y ^ k[u].z ^ k[u].w ^ v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // mode B: unit = chunk of `chunk` tokens, all heads; wave w: heads 4 (w & 1) .. +3 (1 KB of the row), tokens of parity w >> 1
 template <int TPQ>
 __global__ __launch_bounds__(256, 4) void gather_b(const char* __restrict__ kc, const char* __restrict__ vc, const int* __restrict__ idx,
@@ -225,6 +260,10 @@ int main(int argc, char** argv) {
             const int* base = l.list;
             snprintf(name, sizeof name, "A  [slot][head] rows, %s, grid=2048", l.what);
             timeit(name, [&](int r) { hipLaunchKernelGGL(gather_a<2>, dim3(2048), dim3(256), 0, 0, kc, vc, base + (size_t)(r % windows) * tokens, tokens, 128, sink); });
+            for (int rot : {8, 16, 48}) {
+                snprintf(name, sizeof name, "A  rows, head h starts %d*h tokens in, %s", rot, l.what);
+                timeit(name, [&](int r) { hipLaunchKernelGGL(gather_a_rot<2>, dim3(2048), dim3(256), 0, 0, kc, vc, base + (size_t)(r % windows) * tokens, tokens, 128, rot, sink); });
+            }
             snprintf(name, sizeof name, "A' [head][slot] pools, %s, grid=2048", l.what);
             timeit(name, [&](int r) { hipLaunchKernelGGL(gather_a_headpools<2>, dim3(2048), dim3(256), 0, 0, kc, vc, base + (size_t)(r % windows) * tokens, tokens, 128, pool_bytes, sink); });
         }
