@@ -473,6 +473,9 @@ def main():
     if plain_wall is not None:
         result["value_without_run_ahead"] = round(sum(max_tokens) / plain_wall, 2)
         result["ms_per_step_without_run_ahead"] = round(plain_wall * 1e3, 2)
+    sizes = list(runner.graph.captured_bs) if runner.graph is not None else []
+    result["config"]["hipgraph_batch_sizes"] = (f"{len(sizes)} sizes up to {sizes[-1]}" if sizes else "none") + \
+        (f"; dropped as slower than a larger size: {runner.graph_sizes_dropped}" if runner.graph_sizes_dropped else "")
     if world > 1:
         from nano_vllm_x_amd import distributed as tpd
         result["config"]["all_reduce"] = tpd.PEER_STATE      # which path the decode-sized all-reduces took
@@ -480,8 +483,6 @@ def main():
         result["config"]["world_size"] = torch.distributed.get_world_size()
         result["config"]["hipgraph_decode_steps"], result["config"]["eager_decode_steps"] = graph_steps, eager_steps
         result["config"]["sharded_sampling_steps"] = stats1.get("sharded_sampling_steps", 0) - stats0.get("sharded_sampling_steps", 0)
-        sizes = list(runner.graph.captured_bs) if runner.graph is not None else []
-        result["config"]["hipgraph_batch_sizes"] = f"{len(sizes)} sizes up to {sizes[-1]}" if sizes else "none"
     if rank == 0 and not args.no_roofline:
         batches, n_dec, kv_rows = decode_batches_of_workload(prompts, max_tokens, eng.kv_cache_size, args.max_bs,
                                                              args.context_len, args.roofline_every)

@@ -62,6 +62,12 @@ class HIPGraph:
         assert self.graphs and bs <= self.max_bs
         return self.captured_bs[bisect.bisect_left(self.captured_bs, bs)]
 
+    def drop(self, bs: int):
+        """Forget the graph of one batch size: batches of that size then replay the next larger one."""
+        assert bs in self.graphs and bs != self.max_bs
+        del self.graphs[bs]
+        self.captured_bs.remove(bs)
+
     def clear(self):
         self.graphs.clear()
         self.captured_bs.clear()

@@ -67,6 +67,8 @@ class ModelRunner:
         self._stage_output, self._defer_stage_send = None, False
         self._last_done = 0.0
         self.stats = {"prefill_steps": 0, "decode_steps": 0, "graph_steps": 0, "eager_decode_steps": 0, "prefill_s": 0.0, "decode_s": 0.0}
+        self.graph_sizes_dropped: list = []               # decode batch sizes whose graph was slower than a larger one's
+        self.graph_step_us_by_size: dict = {}
         self.graph_capture_error: Optional[str] = None    # set when a tensor-parallel decode graph could not be captured
         # NVX_TP_SAMPLE=gather: tensor-parallel ranks always gather the logits and sample whole rows, as the reference does
         self.shard_sampling = os.environ.get("NVX_TP_SAMPLE", "shard") != "gather"
@@ -437,6 +439,39 @@ class ModelRunner:
         for bs in reversed(sizes):
             with self.graph.capture(bs):
                 hidden_out[:bs] = self._decode_forward(bs)
+        torch.cuda.synchronize()
+        if os.environ.get("NVX_GRAPH_PRUNE", "1") != "0":
+            self.prune_slow_graph_sizes()
+
+    def prune_slow_graph_sizes(self, reps: int = 3, margin: float = 1.04):
+        """A padded batch costs what its projections cost at that many rows, and a BLAS library's choice of kernel is not
+        monotonic in the rows (Qwen3-8B's down projection on this stack: 90 us at 192 rows, 52 at 208).  Every captured
+        size is replayed on padding rows and timed; a size that is slower than a LARGER one (by more than `margin`) is
+        dropped, so its batches replay the larger graph.  All ranks of a group take the slowest rank's times and so
+        drop the same sizes."""
+        sizes = list(self.graph.captured_bs)
+        if len(sizes) < 2:
+            return
+        self.block_table.step_dev.zero_()     # batch = 0: every row is a padding row, as during capture
+        times = {}
+        for bs in sizes:
+            self.graph.replay(bs)             # (first replay of a graph uploads it)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                self.graph.replay(bs)
+            b.record()
+            b.synchronize()
+            us = int(a.elapsed_time(b) * 1e3 / reps)
+            times[bs] = -tpd.all_ranks_min_int(-us, self.device)      # (the slowest rank's; one rank: its own)
+        dropped = []
+        for i, bs in enumerate(sizes[:-1]):
+            best_larger = min(times[b2] for b2 in sizes[i + 1:])
+            if times[bs] > margin * best_larger:
+                dropped.append(bs)
+        for bs in dropped:
+            self.graph.drop(bs)
+        self.graph_sizes_dropped, self.graph_step_us_by_size = dropped, times
         torch.cuda.synchronize()
 
     # -- bookkeeping ---------------------------------------------------------------------------------

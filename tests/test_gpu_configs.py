@@ -208,3 +208,44 @@ def test_config5_4096_token_context_in_chunks_at_32b_rank_geometry():
     assert out[True][3]["graph_steps"] == 5 and out[True][3]["eager_decode_steps"] == 0
     for sid, _, _ in reqs:
         check_logits("config5_chunked_vs_one_step_prefill", np.stack(out[True][1][sid]), np.stack(out[False][1][sid]), sid)
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_a_batch_replayed_from_a_larger_graph_gets_the_same_bits():
+    """ModelRunner.prune_slow_graph_sizes drops a captured size that is slower than a larger one; its batches then run
+    padded to the larger size.  Rows of a batch do not see the padding rows: with every size but the largest dropped
+    (margin 0), the same teacher-forced history gives bit-identical logits at every step."""
+    from nano_vllm_x_amd import qwen3
+    from nano_vllm_x_amd.core.engine import EngineCore
+    from nano_vllm_x_amd.core.model_runner import ModelRunner
+
+    cfg = qwen3.Qwen3Config(vocab_size=1024, hidden_size=1024, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=16,
+                            num_key_value_heads=8, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in (5, 40, 17, 64, 9)]
+    n_new, slots, max_bs, ctx = 6, 2048, 48, 256
+    runner = ModelRunner(model="graph-sizes", max_bs=max_bs, enforce_eager=False, context_len=ctx, config=cfg, seed=1)
+    runner.load_model(state_dict_iter=qwen3.random_checkpoint(cfg, 9))
+    runner.initialize_kv_cache(slots)
+    assert runner.graph.captured_bs[-1] == max_bs and len(runner.graph.captured_bs) + len(runner.graph_sizes_dropped) == 7
+    assert set(runner.graph_step_us_by_size) == {1, 2, 4, 8, 16, 32, 48}
+
+    def run(forced=None):
+        core = EngineCore(kv_cache_size=slots, max_bs=max_bs, context_len=ctx)
+        reqs = [(str(i), p, n_new) for i, p in enumerate(prompts)]
+        with torch.inference_mode():
+            toks, logits, _ = _forced_run(core, runner, reqs, forced)
+        for s in list(core.scheduler.running):
+            runner.release_sequence(s)
+        return toks, logits
+
+    toks, want = run()
+    before = runner.stats["graph_steps"]
+    assert before == n_new - 1
+    runner.prune_slow_graph_sizes(margin=0.0)
+    assert runner.graph.captured_bs == [max_bs] and runner.graph.match_bs(5) == max_bs
+    _toks, got = run(forced=toks)
+    assert runner.stats["graph_steps"] == 2 * before and runner.stats["eager_decode_steps"] == 0
+    for sid in want:
+        for a, b in zip(want[sid], got[sid]):
+            assert np.array_equal(a, b)
