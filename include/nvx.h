@@ -41,7 +41,7 @@ typedef void* nvx_stream_t;
  *   2: nvx_decode_step_setup gained `prev_ids`.
  *   3: float16 entry points (`*_f16`) added.
  *   4: direct-peer all-reduce (`nvx_peer_*`) and sharded sampling (`nvx_sample_shard`, `nvx_sample_pick`) added. */
-#define NVX_ABI_VERSION 6
+#define NVX_ABI_VERSION 7
 
 /* Library identification and diagnostics. */
 int nvx_abi_version(void);
@@ -323,6 +323,19 @@ int nvx_splitk_sum(const float* partials, int n_splits, int64_t rows, int64_t n,
                    nvx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The same projections at up to 256 rows (F.linear of the parallel linears on decode batches,
+ * nanovllmx/layers/linear.py:167-176,266-280, with SiluAndMul, nanovllmx/layers/activation.py:15-18): the weight, packed by
+ * nvx_lmhead_pack, is streamed once by workgroups that own 128 of its rows over one slice of k, while the batch's rows
+ * pass through LDS in chunks of 128 k.  k must be a multiple of 512 x k_slices.
+ * mode 0: y 16-bit (m, n).   mode 1: the weight is [gate rows; up rows]; y 16-bit (m, n / 2) = SiluAndMul of the
+ * 16-bit-rounded projection.   mode 2: y fp32 (k_slices, m, n) partial products for nvx_rmsnorm_splitk / nvx_splitk_sum;
+ * nvx_linear_block_slices(n, k, mode) proposes k_slices (1 for modes 0 and 1; 0 = shape not supported). */
+int64_t nvx_linear_block_max_rows(void);
+int nvx_linear_block_slices(int64_t n, int64_t k, int mode);
+int nvx_linear_block(const void* w_packed, int64_t n, int64_t k, const void* x, int64_t x_row_stride, int64_t m,
+                     int mode, int k_slices, void* y, nvx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Tensor-parallel all-reduce of a decode step, over memory the peers have mapped, fused with the
  * RMSNorm that follows it.  Replaces the NCCL all-reduce behind the row-parallel linears and the
  * vocab-parallel embedding (nanovllmx/distributed/communication_op.py:41-52,153-156, called from
@@ -419,6 +432,8 @@ int nvx_linear_stream_f16(const void* w_packed, int64_t n, int64_t k, const void
                           float* partials, nvx_stream_t stream);
 int nvx_splitk_sum_f16(const float* partials, int n_splits, int64_t rows, int64_t n, int silu_mul, void* y,
                        nvx_stream_t stream);
+int nvx_linear_block_f16(const void* w_packed, int64_t n, int64_t k, const void* x, int64_t x_row_stride, int64_t m,
+                         int mode, int k_slices, void* y, nvx_stream_t stream);
 int nvx_lmhead_sample_f16(const void* w_packed, int64_t n_rows, int64_t k, const void* x, int64_t x_row_stride,
                           int64_t batch, const float* temperatures, int64_t vocab_offset, int64_t vocab,
                           uint64_t seed, uint64_t offset, void* ws, int64_t ws_bytes, uint64_t* key_out,

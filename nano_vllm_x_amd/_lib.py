@@ -76,6 +76,9 @@ SIGNATURES = {
                                    _c_vp, _c_vp, _c_i64, _c_vp]),
     "nvx_linear_stream": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "nvx_splitk_sum": (_c_i32, [_c_vp, _c_i32, _c_i64, _c_i64, _c_i32, _c_vp, _c_vp]),
+    "nvx_linear_block_max_rows": (_c_i64, []),
+    "nvx_linear_block_slices": (_c_i32, [_c_i64, _c_i64, _c_i32]),
+    "nvx_linear_block": (_c_i32, [_c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i32, _c_i32, _c_vp, _c_vp]),
     "nvx_peer_allreduce_norm": (_c_i32, [_c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_f32, _c_vp]),
 }
 
@@ -88,7 +91,8 @@ class NvxLibraryError(RuntimeError):
 
 # entry points that also exist as `<name>_f16` (IEEE half build of the same source, same signature)
 F16_ENTRY_POINTS = ("nvx_rmsnorm", "nvx_rope", "nvx_qknorm_rope_store", "nvx_silu_mul", "nvx_linear_decode", "nvx_rmsnorm_splitk",
-                    "nvx_paged_decode", "nvx_paged_decode_qkv", "nvx_paged_prefill", "nvx_peer_allreduce_norm", "nvx_lmhead_sample", "nvx_linear_stream", "nvx_splitk_sum")
+                    "nvx_paged_decode", "nvx_paged_decode_qkv", "nvx_paged_prefill", "nvx_peer_allreduce_norm", "nvx_lmhead_sample", "nvx_linear_stream", "nvx_splitk_sum",
+                    "nvx_linear_block")
 for _name in F16_ENTRY_POINTS:
     SIGNATURES[_name + "_f16"] = SIGNATURES[_name]
 

@@ -220,38 +220,41 @@ extern "C" int NVX_ENTRY(nvx_rmsnorm)(const void* x, int64_t x_row_stride, const
 // 256-thread workgroup takes one row (one wave per row would leave most of the chip idle and make
 // every lane walk splits x row/512 loads): thread t owns elements 4t .. 4t+3 of every 1024-wide
 // slab, all loads are issued at once, the sum of squares crosses the waves through LDS.
-template <int SLABS, bool HAS_RES>
-__global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
+template <int SLABS, bool HAS_RES, int NT>
+__global__ __launch_bounds__(NT) void rmsnorm_splitk_kernel(
     const float* __restrict__ partials, int n_splits, const uint16_t* residual, const uint16_t* __restrict__ weight,
     uint16_t* y, uint16_t* residual_out, int rows, int hidden, float eps) {
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
     const int tid = threadIdx.x;
     const int row = blockIdx.x;
     const int64_t split_stride = (int64_t)rows * hidden;
     float v[SLABS][4];
     uint2 wv[SLABS];
     float ss = 0.f;
-    // The kernel is a chain of memory round trips and little else, so every load of a slab (up to four
-    // splits at a time, the residual, the weight) is issued before the first use.  With a plain loop over
+    // The kernel is a chain of memory round trips and little else, so every load of a slab (up to four or
+    // eight splits at a time, the residual, the weight) is issued before the first use.  With a plain loop over
     // the splits the compiler waited for each load before issuing the next: six round trips in a row.
+    // Wide rows (hidden > 1024) get 1024 threads, so that a 4096-wide row is ONE slab: with 256 threads its four
+    // slabs were walked one after the other, 4 x ceil(splits / 4) round trips (8 us for 8 splits where this takes 4).
 #pragma unroll
     for (int it = 0; it < SLABS; ++it) {
-        const int col = it * 1024 + tid * 4;
+        const int col = it * (4 * NT) + tid * 4;
         if (col < hidden) {
             const float* p = partials + (int64_t)row * hidden + col;
             uint2 r = make_uint2(0u, 0u);
             if (HAS_RES) r = *reinterpret_cast<const uint2*>(residual + (int64_t)row * hidden + col);
             wv[it] = *reinterpret_cast<const uint2*>(weight + col);
             nvx_f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < n_splits; s0 += 4) {
-                nvx_f32x4 b[4];
+            constexpr int UNR = NT == 256 ? 4 : 8;   // splits in flight (narrow rows come from projections cut into <= 4)
+            for (int s0 = 0; s0 < n_splits; s0 += UNR) {
+                nvx_f32x4 b[UNR];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {   // splits past the end re-read split 0 (cached) and are not added
+                for (int j = 0; j < UNR; ++j) {   // splits past the end re-read split 0 (cached) and are not added
                     const int sidx = s0 + j < n_splits ? s0 + j : 0;
                     b[j] = *reinterpret_cast<const nvx_f32x4*>(p + sidx * split_stride);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {   // same order of additions as a loop over the splits
+                for (int j = 0; j < UNR; ++j) {   // same order of additions as a loop over the splits
                     if (s0 + j == 0) a = b[j];
                     else if (s0 + j < n_splits) a += b[j];
                 }
@@ -273,11 +276,13 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    ss = red[0] + red[1] + red[2] + red[3];
+    ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) ss += red[w];
     const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
 #pragma unroll
     for (int it = 0; it < SLABS; ++it) {
-        const int col = it * 1024 + tid * 4;
+        const int col = it * (4 * NT) + tid * 4;
         if (col < hidden) {
             *reinterpret_cast<uint2*>(y + (int64_t)row * hidden + col) =
                 make_uint2(pack_h16x2((v[it][0] * inv) * h16lo_to_f32(wv[it].x), (v[it][1] * inv) * h16hi_to_f32(wv[it].x)),
@@ -286,13 +291,13 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_kernel(
     }
 }
 
-template <int SLABS>
+template <int SLABS, int NT>
 static void launch_rmsnorm_splitk(const float* p, int s, const void* res, const void* w, void* y, void* ro, int rows, int hidden,
                                   float eps, hipStream_t st) {
-    const dim3 grid((unsigned)rows), block(256);
-    if (res) hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, true>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+    const dim3 grid((unsigned)rows), block(NT);
+    if (res) hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, true, NT>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
                                 (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
-    else hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, false>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
+    else hipLaunchKernelGGL((rmsnorm_splitk_kernel<SLABS, false, NT>), grid, block, 0, st, p, s, (const uint16_t*)res, (const uint16_t*)w,
                             (uint16_t*)y, (uint16_t*)ro, rows, hidden, eps);
 }
 
@@ -309,11 +314,10 @@ extern "C" int NVX_ENTRY(nvx_rmsnorm_splitk)(const float* partials, int n_splits
                 NVX_EINVAL, "nvx_rmsnorm_splitk: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int h = (int)hidden, r = (int)rows;
-    if (h <= 1024) launch_rmsnorm_splitk<1>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 2048) launch_rmsnorm_splitk<2>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 4096) launch_rmsnorm_splitk<4>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else if (h <= 5120) launch_rmsnorm_splitk<5>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
-    else launch_rmsnorm_splitk<8>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    if (h <= 1024) launch_rmsnorm_splitk<1, 256>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 2048) launch_rmsnorm_splitk<1, 512>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else if (h <= 4096) launch_rmsnorm_splitk<1, 1024>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
+    else launch_rmsnorm_splitk<2, 1024>(partials, n_splits, residual, weight, y, residual_out, r, h, eps, st);
     return nvx_check_launch("nvx_rmsnorm_splitk");
 }
 

@@ -474,6 +474,37 @@ def linear_stream(x, packed, n: int, out=None):
     return out
 
 
+def linear_block_max_rows() -> int:
+    return int(_lib.load().nvx_linear_block_max_rows())
+
+
+def linear_block_slices(n: int, k: int, mode: int) -> int:
+    """k-slices linear_block cuts a weight of n rows over k into (mode 2), 1 for modes 0 / 1; 0 = shape not supported."""
+    return int(_lib.load().nvx_linear_block_slices(n, k, mode))
+
+
+def linear_block(x, packed, n: int, mode: int = 0, k_slices: int = 1, out=None):
+    """x (m, k) 16-bit, m <= 256; `packed` = lmhead_pack of the (n, k) weight.  mode 0: y (m, n); mode 1: the weight is
+    [gate rows; up rows], y (m, n / 2) = SiluAndMul of the 16-bit-rounded projection; mode 2: fp32 partial products
+    (k_slices, m, n) for rmsnorm_splitk / splitk_sum to add up."""
+    _dev(x, packed, out)
+    _need(x.dim() == 2 and x.stride(1) == 1 and x.dtype in H16 and packed.dtype == x.dtype and packed.is_contiguous(), "linear_block: x / packed layout")
+    m, k = x.shape
+    _need(0 < m <= linear_block_max_rows(), "linear_block: 1..256 rows")
+    _need(n % 16 == 0 and packed.numel() == n * k, "linear_block: packed weight size")
+    _need(mode in (0, 1, 2) and k_slices >= 1 and (mode == 2 or k_slices == 1), "linear_block: mode / k_slices")
+    shape = (k_slices, m, n) if mode == 2 else (m, n // 2 if mode == 1 else n)
+    dtype = torch.float32 if mode == 2 else x.dtype
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=x.device)
+    else:
+        _need(out.dtype == dtype and out.is_contiguous() and tuple(out.shape) == shape, "linear_block: out")
+    lib = _lib.load()
+    _lib.check(_fn(lib, "nvx_linear_block", x.dtype)(_ptr(packed), n, k, _ptr(x), x.stride(0), m, mode, k_slices, _ptr(out), _stream()),
+               "nvx_linear_block")
+    return out
+
+
 def lmhead_rows_per_pass() -> int:
     return int(_lib.load().nvx_lmhead_rows_per_pass())
 

@@ -104,13 +104,21 @@ def linear_fp32(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return F.linear(x.float(), weight.float()).to(x.dtype)
 
 
-# The streamed projection (ops.linear_stream) takes the gate/up weight of a decode step when it is at least this large and
-# the batch at most this tall; NVX_LINEAR_STREAM=0 keeps the library projection.
-STREAM_MIN_WEIGHT_BYTES = 128 << 20
-STREAM_GATEUP_MAX_ROWS = 16
+# The blocked projection (ops.linear_block: weight streamed from a tiled copy, the batch's rows through LDS in chunks of k)
+# takes the MLP weights of a decode step when they are at least this large: gate/up (with SiluAndMul in its epilogue) up to
+# BLOCK_GATEUP_MAX_ROWS rows, down (fp32 partials per k-slice for the RMSNorm that follows) from BLOCK_DOWN_MIN_ROWS to
+# BLOCK_DOWN_MAX_ROWS rows, on a single rank (a tensor-parallel rank hands its partial result to the all-reduce in 16 bits).
+# Qwen3-8B, us per layer with the weight coming from HBM (tools/kernel_bench.py block; library = GEMM + its consumer):
+# gate/up 38.7 / 39.0 / 40.9 / 44.9 against 49.6 / 48.3 / 49.2 / 50.7 at 24 / 32 / 64 / 96 rows (55 against 54 at 128);
+# down + norm 26 / 29 / 35 / 39 / 50 / 52 against 29 / 41 / 58 / 70 / 80 / 94 at 24 / 64 / 96 / 128 / 160 / 192 rows (below 17
+# rows the library's 24 us stand; from 208 rows its 54-59 us do: there the products, not the stream, set this kernel's pace).  qkv and o (<= 50 MB) are level with the library once their consumer is counted and stay with it.
+# NVX_LINEAR_BLOCK=0 keeps the library projections.
+BLOCK_MIN_WEIGHT_BYTES = 64 << 20
+BLOCK_GATEUP_MAX_ROWS = 96
+BLOCK_DOWN_MIN_ROWS, BLOCK_DOWN_MAX_ROWS = 17, 192
 
 
-def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Optional[torch.Tensor] = None, k_slices: int = 0) -> torch.Tensor:
     """Projection of a decode batch.  Returns bf16 (rows, n) -- or, for the row-parallel projections
     ("o", "down") on a single rank, fp32 partial products (splits, rows, n) that the RMSNorm which
     follows sums (under tensor parallelism they stay 16-bit: the sum over ranks comes first);
@@ -132,16 +140,15 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, packed: Opti
         splits = ops.linear_decode_splits(n, k) if use and n % 16 == 0 else 0
         if splits:
             return ops.linear_decode(x, weight, mode=2, k_splits=splits)
+        if packed is not None and k_slices and BLOCK_DOWN_MIN_ROWS <= rows <= BLOCK_DOWN_MAX_ROWS and x.stride(1) == 1:
+            return ops.linear_block(x, packed, n, mode=2, k_slices=k_slices)
         return F.linear(x, weight)
     fits = use and k in (512, 768, 1024)
     if kind == "gate_up":
         if fits and (n // 2) % 16 == 0:
             return ops.linear_decode(x, weight, mode=1)
-        if packed is not None and rows <= STREAM_GATEUP_MAX_ROWS and x.stride(1) == 1:
-            # a weight of hundreds of MB: streamed once with the rows resident on every CU, SiluAndMul in the kernel that sums
-            # the K-slices' partials (Qwen3-8B, us per layer with the weight coming from HBM: 41 / 44 against 47 / 46 for the
-            # library projection + SiluAndMul at 1 / 16 rows, 51 against 48 at 29 rows; tools/kernel_bench.py stream)
-            return ops.splitk_sum(ops.linear_stream(x, packed, n), x.dtype, silu_mul=True)
+        if packed is not None and rows <= BLOCK_GATEUP_MAX_ROWS and x.stride(1) == 1:
+            return ops.linear_block(x, packed, n, mode=1)
         return ops.silu_mul(F.linear(x, weight))
     if fits and n % 16 == 0:
         return ops.linear_decode(x, weight, mode=0)
@@ -213,17 +220,31 @@ class Qwen3MLP(nn.Module):
         self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * inter, bias=False)
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
         self.act_fn = SiluAndMul()
-        self.gate_up_packed: Optional[torch.Tensor] = None    # tiled copy for ops.linear_stream (large weights only)
+        # tiled copies for ops.linear_block (large weights only; see BLOCK_MIN_WEIGHT_BYTES)
+        self.gate_up_packed: Optional[torch.Tensor] = None
+        self.down_packed: Optional[torch.Tensor] = None
+        self.down_slices = 0
 
     def pack_decode_weights(self):
+        if os.environ.get("NVX_LINEAR_BLOCK", "1") == "0":
+            return
+
+        def wants(w):
+            return w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.numel() * w.element_size() >= BLOCK_MIN_WEIGHT_BYTES
+
         w = self.gate_up_proj.weight
-        if (os.environ.get("NVX_LINEAR_STREAM", "1") != "0" and w.is_cuda and w.dtype in (torch.bfloat16, torch.float16)
-                and w.numel() * w.element_size() >= STREAM_MIN_WEIGHT_BYTES and w.shape[1] % 1024 == 0 and w.shape[0] % 8 == 0):
+        if wants(w) and ops.linear_block_slices(w.shape[0], w.shape[1], 1) > 0:
             self.gate_up_packed = ops.lmhead_pack(w.detach())
+        w = self.down_proj.weight
+        if wants(w) and not tpd.collectives_active():
+            self.down_slices = ops.linear_block_slices(w.shape[0], w.shape[1], 2)
+            if self.down_slices > 0:
+                self.down_packed = ops.lmhead_pack(w.detach())
 
     def forward(self, x, decode: bool = False):
         if decode:
-            out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up", self.gate_up_packed), self.down_proj.weight, "down")
+            out = decode_linear(decode_linear(x, self.gate_up_proj.weight, "gate_up", self.gate_up_packed), self.down_proj.weight, "down",
+                                self.down_packed, self.down_slices)
             return out if out.dtype == torch.float32 else tpd.tp_reduce_later(out)
         if FP32_LINEAR:
             return tpd.tp_reduce_later(linear_fp32(self.act_fn(linear_fp32(x, self.gate_up_proj.weight)), self.down_proj.weight))

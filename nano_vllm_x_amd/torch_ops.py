@@ -27,6 +27,7 @@ _DEFS = {
     "sample_pick": "(Tensor winners) -> Tensor",
     "lmhead_pack": "(Tensor weight) -> Tensor",
     "linear_stream": "(Tensor x, Tensor packed, int n) -> Tensor",
+    "linear_block": "(Tensor x, Tensor packed, int n, int mode, int k_slices) -> Tensor",
     "splitk_sum": "(Tensor partials, bool half, bool silu_mul) -> Tensor",
     "lmhead_sample": "(Tensor packed, int n_rows, Tensor x, Tensor temperatures, int vocab_offset, int vocab, int seed, int offset, "
                      "bool keys) -> Tensor",
@@ -103,6 +104,10 @@ def _sample_pick(winners):
 
 def _linear_stream(x, packed, n):
     return ops.linear_stream(x, packed, n)
+
+
+def _linear_block(x, packed, n, mode, k_slices):
+    return ops.linear_block(x, packed, n, mode=mode, k_slices=k_slices)
 
 
 def _splitk_sum(partials, half, silu_mul):

@@ -107,10 +107,12 @@ def test_every_kernel_entry_point_has_a_custom_op():
              "nvx_sample": "sample", "nvx_sampler_probs": "sampler_probs", "nvx_block_table_write_rows": "block_table_write_rows",
              "nvx_decode_step_setup": "decode_step_setup", "nvx_peer_allreduce_norm": "peer_allreduce_norm",
              "nvx_sample_shard": "sample_shard", "nvx_sample_pick": "sample_pick", "nvx_lmhead_pack": "lmhead_pack",
-             "nvx_lmhead_sample": "lmhead_sample", "nvx_linear_stream": "linear_stream", "nvx_splitk_sum": "splitk_sum"}
+             "nvx_lmhead_sample": "lmhead_sample", "nvx_linear_stream": "linear_stream", "nvx_splitk_sum": "splitk_sum",
+             "nvx_linear_block": "linear_block"}
     helpers = {"nvx_abi_version", "nvx_last_error", "nvx_linear_decode_splits", "nvx_decode_plan_ws_ints", "nvx_decode_partial_ws_floats",
                "nvx_prefill_plan_ws_ints", "nvx_sample_ws_bytes", "nvx_paged_decode_noalloc_max_batch",
                "nvx_lmhead_max_rows", "nvx_lmhead_rows_per_pass", "nvx_lmhead_packed_elems", "nvx_lmhead_ws_bytes",
+               "nvx_linear_block_max_rows", "nvx_linear_block_slices",
                # start-up calls of the direct-peer exchange (allocation, handle exchange, status, teardown): host side
                "nvx_peer_exchange_bytes", "nvx_peer_create", "nvx_peer_export", "nvx_peer_import", "nvx_peer_status", "nvx_peer_destroy"}
     # the float16 entry points have no operator of their own: the operator of the bfloat16 one picks them by tensor dtype

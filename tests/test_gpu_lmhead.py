@@ -147,3 +147,42 @@ def test_streamed_projection_and_its_consumers(ops, m, n, k):
         yr, rr = rmsnorm_oracle(y.cpu(), nw.cpu(), 1e-6, res.cpu())
         assert torch.equal(ro.cpu().view(torch.int16), rr.view(torch.int16))
         assert (yn.cpu().view(torch.int16).int() - yr.view(torch.int16).int()).abs().max().item() <= 1
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (2048, 512), (4096, 12288), (48, 1024), (4112, 1536)])
+def test_blocked_projection_matches_fp32_matmul_and_its_fused_epilogues(ops, n, k):
+    """nvx_linear_block (the weight streamed from the tiled copy, the rows through LDS in chunks of k) against a torch
+    fp32 matmul of the same 16-bit operands: mode 0 within the output rounding (2^-8 |ref| + 1e-3), the k-slices'
+    partials of mode 2 sum to the product within fp32 summation error and feed nvx_rmsnorm_splitk as the partials of the
+    skinny kernel do, and the SiluAndMul epilogue (mode 1) is bit-equal to nvx_silu_mul of mode 0's rounded output (same
+    accumulation order, same roundings).  Ragged rows (17, 33, 65, 100, 129, 200), ragged tiles (n = 48, 4112), both formats."""
+    gen = torch.Generator().manual_seed(n + k)
+    for dtype in (torch.bfloat16, torch.float16):
+        w = (torch.randn(n, k, generator=gen) * k ** -0.5).to(dtype).to(DEV)
+        packed = ops.lmhead_pack(w)
+        slices = ops.linear_block_slices(n, k, 2)
+        assert slices >= 1 and (k // 512) % slices == 0
+        for m in (1, 17, 32, 33, 65, 100, 128, 129, 192, 200, 256):
+            x = torch.randn(m, k, generator=gen).to(dtype).to(DEV)
+            want = x.float() @ w.float().t()
+            y = ops.linear_block(x, packed, n, mode=0)
+            ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+            assert ((y.float() - want).abs() <= want.abs() * ulp + 1e-3).all(), (m, (y.float() - want).abs().max())
+            parts = ops.linear_block(x, packed, n, mode=2, k_slices=slices)
+            assert parts.shape == (slices, m, n)
+            torch.testing.assert_close(parts.sum(0), want, rtol=1e-4, atol=2e-4)
+            if n % 32 == 0:
+                assert torch.equal(ops.linear_block(x, packed, n, mode=1), ops.silu_mul(y))
+            if n % 8 == 0 and dtype == torch.bfloat16:
+                nw = torch.randn(n, generator=gen).to(dtype).to(DEV)
+                res = torch.randn(m, n, generator=gen).to(dtype).to(DEV)
+                summed = parts[0].clone()             # the slices added in order, as the norm kernel adds them
+                for sl in range(1, slices):
+                    summed += parts[sl]
+                y_ref, r_ref = ops.rmsnorm(summed.to(dtype), nw, 1e-6, residual=res)
+                y2, r2 = ops.rmsnorm_splitk(parts, nw, 1e-6, residual=res)
+                assert torch.equal(r2, r_ref)
+                assert (y2.view(torch.int16).int() - y_ref.view(torch.int16).int()).abs().max() <= 2
+    with pytest.raises(RuntimeError, match="256 rows"):
+        ops.linear_block(torch.zeros(257, k, dtype=packed.dtype, device=DEV), packed, n)
+    assert ops.linear_block_slices(4096, 4096 + 128, 2) == 0      # k not a whole number of ring turns

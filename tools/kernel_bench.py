@@ -306,6 +306,49 @@ def cmd_stream(args):
             del ws, packed
 
 
+def cmd_block(args):
+    """Decode-step projections of Qwen3-8B at 17..128 rows: the blocked projection (+ its consumer) against torch (hipBLASLt)."""
+    import torch.nn.functional as F
+    shapes = [("qkv", 6144, 4096, 2, "sum"), ("o", 4096, 4096, 2, "norm"), ("gate_up+silu", 24576, 4096, 1, "none"), ("down", 4096, 12288, 2, "norm")]
+    for m in ((int(os.environ["NVX_BENCH_M"]),) if os.environ.get("NVX_BENCH_M") else (24, 32, 48, 64, 96, 128)):
+        for name, n, k, mode, consumer in shapes:
+            copies = max(3, -(-(768 << 20) // (n * k * 2)))
+            ws = [(torch.randn(n, k, device=DEV) * k ** -0.5).to(torch.bfloat16) for _ in range(copies)]
+            packed = [ops.lmhead_pack(w) for w in ws]
+            x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+            nw = torch.ones(n, device=DEV, dtype=torch.bfloat16)
+            res = torch.randn(m, n, device=DEV).to(torch.bfloat16)
+            s = ops.linear_block_slices(n, k, mode)
+            out = torch.empty((s, m, n) if mode == 2 else (m, n // 2), dtype=torch.float32 if mode == 2 else torch.bfloat16, device=DEV)
+            i = [0]
+
+            def ours():
+                i[0] += 1
+                ops.linear_block(x, packed[i[0] % copies], n, mode=mode, k_slices=s, out=out)
+                if consumer == "sum":
+                    ops.splitk_sum(out, torch.bfloat16)
+                elif consumer == "norm":
+                    ops.rmsnorm_splitk(out, nw, 1e-6, residual=res)
+
+            def kernel_only():
+                i[0] += 1
+                ops.linear_block(x, packed[i[0] % copies], n, mode=mode, k_slices=s, out=out)
+
+            def lib():
+                i[0] += 1
+                y = F.linear(x, ws[i[0] % copies])
+                if mode == 1:
+                    ops.silu_mul(y)
+                elif consumer == "norm":
+                    ops.rmsnorm(y, nw, 1e-6, res)
+
+            t_ours, t_k, t_lib = timed(ours, args.reps), timed(kernel_only, args.reps), timed(lib, args.reps)
+            print(json.dumps({"kernel": "linear_block+consumer", "layer": name, "M": m, "N": n, "K": k, "slices": s, "us": round(t_ours * 1e6, 2),
+                              "kernel_alone_us": round(t_k * 1e6, 2), "hipblaslt_path_us": round(t_lib * 1e6, 2),
+                              "weight_GBps_kernel": round(n * k * 2 / t_k / 1e9)}), flush=True)
+            del ws, packed
+
+
 def cmd_linear(args):
     """Decode-step projections of Qwen3-0.6B: this library's skinny kernel vs torch (hipBLASLt)."""
     import torch.nn.functional as F
@@ -351,7 +394,7 @@ def cmd_linear(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead", "stream"])
+    ap.add_argument("cmd", choices=["decode", "prefill", "sampler", "linear", "qknorm", "lmhead", "stream", "block"])
     ap.add_argument("--every", type=int, default=8)
     ap.add_argument("--tp", type=int, default=1, help="linear: the shapes of one rank of a tensor-parallel job")
     ap.add_argument("--reps", type=int, default=28)
@@ -362,4 +405,4 @@ if __name__ == "__main__":
     ap.add_argument("--uniform-len", type=int, default=0)
     ap.add_argument("--heads", type=str, default="", help="query,kv head counts, e.g. 32,8 (default 16,8)")
     a = ap.parse_args()
-    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear, "lmhead": cmd_lmhead, "stream": cmd_stream}[a.cmd](a)
+    {"decode": cmd_decode, "prefill": cmd_prefill, "sampler": cmd_sampler, "qknorm": cmd_qknorm, "linear": cmd_linear, "lmhead": cmd_lmhead, "stream": cmd_stream, "block": cmd_block}[a.cmd](a)
