@@ -87,7 +87,11 @@ def _peer_worker(rank, tp, port, q, dtype_name, hidden):
             ref = ops.rmsnorm_splitk(want_sum.float()[None].contiguous(), weight, EPS, residual=res)
             y, r_out = (out, None) if mode == 1 else out
             y_ref, r_ref = (ref, None) if mode == 1 else ref
-            assert torch.equal(y, y_ref), f"call {call}: norm differs from the split-K norm of the same sum"
+            if hidden <= 1024:
+                assert torch.equal(y, y_ref), f"call {call}: norm differs from the split-K norm of the same sum"
+            else:   # wide rows: the split-K norm sums the squares with 1024 threads, the exchange kernel with 256 -- another order
+                d = (y.view(torch.int16).int() - y_ref.view(torch.int16).int()).abs().max().item()
+                assert d <= 1, f"call {call}: norm is {d} units in the last place from the split-K norm of the same sum"
             if mode == 2:
                 assert torch.equal(r_out, r_ref), f"call {call}: residual differs"
             o = rmsnorm_oracle(want_sum.cpu(), weight.cpu(), EPS, None if res is None else res.cpu())
