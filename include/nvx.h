@@ -290,8 +290,11 @@ int nvx_decode_step_setup(const int32_t* step, int64_t stride, int64_t padded_ba
  * the kernel's loads are whole 1 KB lines that go straight into operand registers.
  *
  * nvx_lmhead_sample: x rows x_row_stride elements apart, batch <= nvx_lmhead_max_rows(), k = 1024.  The batch stays in
- * the LDS of every compute unit, nvx_lmhead_rows_per_pass() rows at a time: a taller batch takes one pass over the
- * weight per such group of rows (measured on Qwen3-0.6B: one pass beats the projection + sampler, two passes do not).  Row r of W is token vocab_offset + r of a vocabulary of `vocab` tokens (a
+ * the LDS of every compute unit, nvx_lmhead_rows_per_pass() rows at a time.  Up to twice that many rows go out as two row
+ * groups in one launch, on workgroups paired within an XCD that take the same tiles (fetched from HBM once, found in L2
+ * the second time); a taller batch takes one pass over the weight per group of rows, one after the other (measured on
+ * Qwen3-0.6B: up to 128 rows this beats the projection + sampler, beyond it does not).  Results do not depend on how the
+ * rows were grouped.  Row r of W is token vocab_offset + r of a vocabulary of `vocab` tokens (a
  * tensor-parallel rank passes its shard; tokens >= vocab are padding and never drawn).  Every logit is rounded to the
  * 16-bit format, as the projection would have stored it; the draw is nvx_sample's (same noise per (seed, offset,
  * row, token), same tie rule; temperature <= 0: arg-max), so key_out / out_ids equal what nvx_sample_shard /

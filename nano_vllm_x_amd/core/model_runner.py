@@ -31,10 +31,11 @@ from .common import ForwardBatch, ForwardMode
 from .hip_graph import HIPGraph, decode_batch_ladder
 from .kv_cache import KVCachePool
 
-# Largest step whose LM head + draw go through ops.lmhead_sample: it takes one pass over the weight per 64 rows, and from
-# the second pass on the library projection + sampler is the faster pair (Qwen3-0.6B, us: 59 vs 87 at 29 rows, 72 vs 97 at
-# 64, 137 vs 119 at 123; tools/kernel_bench.py lmhead)
-LMHEAD_FUSED_MAX_ROWS = int(os.environ.get("NVX_LMHEAD_FUSED_MAX_ROWS", "64"))
+# Largest step whose LM head + draw go through ops.lmhead_sample: it holds 64 rows per compute unit, takes 65..128 rows as two
+# row groups on paired workgroups in one launch (a tile fetched from HBM by one is found in L2 by the other), and more rows as
+# passes that follow one another, where the library projection + sampler is the faster pair (Qwen3-0.6B, us: 60 vs 86 at 29
+# rows, 74 vs 97 at 64, 88 vs 109 at 96, 105 vs 119 at 123, 215 vs 155 at 192; tools/kernel_bench.py lmhead)
+LMHEAD_FUSED_MAX_ROWS = int(os.environ.get("NVX_LMHEAD_FUSED_MAX_ROWS", "128"))
 
 _DTYPES = {"half": torch.float16, "float16": torch.float16, "float": torch.float32, "float32": torch.float32,
            "bfloat16": torch.bfloat16}

@@ -46,10 +46,25 @@ template <int MT, int K>
 __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
     const nvx_u32x4* __restrict__ wp, const uint16_t* __restrict__ x, int64_t x_stride, int m_rows, int row0,
     const float* __restrict__ temps, int n_tiles, int tok0, int tok_end, uint64_t seed, uint64_t offset,
-    unsigned long long* __restrict__ winners, uint16_t* __restrict__ logits_out, int64_t logits_stride) {
-    // x, temps, winners and logits_out point at THIS pass's rows; row0 is the index of the first of them in the batch
-    // (the noise of a row is keyed by its index in the whole batch)
+    unsigned long long* __restrict__ winners, uint16_t* __restrict__ logits_out, int64_t logits_stride, int n_groups, int group_rows) {
+    // x, temps, winners and logits_out point at THIS launch's rows; row0 is the index of the first of them in the batch
+    // (the noise of a row is keyed by its index in the whole batch).
+    // n_groups = 2: the launch holds two row groups of group_rows rows (the second may be shorter: m_rows counts both).
+    // Workgroups b and b + 8 run on the same XCD; they take the SAME tiles, one for each row group, so that a tile is
+    // fetched from HBM once and found in that XCD's L2 by the other -- two passes over the weight for the HBM price of one.
     constexpr int KS = K / 32;
+    const int group = n_groups == 2 ? (blockIdx.x >> 3) & 1 : 0;
+    const int wg = n_groups == 2 ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x;
+    const int wgs = gridDim.x / n_groups;
+    if (n_groups == 2) {
+        const int first = group * group_rows;
+        x += (int64_t)first * x_stride;
+        temps += first;
+        winners += (int64_t)wgs * first;
+        if (logits_out) logits_out += (int64_t)first * logits_stride;
+        row0 += first;
+        m_rows = group == 0 ? group_rows : m_rows - group_rows;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char lmh_smem[];
     nvx_u32x4* xs = reinterpret_cast<nvx_u32x4*>(lmh_smem);   // [MT][KS][64]: the batch rows as B operands
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -59,8 +74,8 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
     // tile's piece right after the products that read it, so a whole tile (32 KB per wave) is always in flight and the
     // draw over the finished tile runs under it.  The first tile is requested before anything else: its trip to HBM
     // and the rows' trip to L2 below then overlap instead of following each other.
-    const int stride_tiles = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
+    const int stride_tiles = wgs * 4;
+    int tile = wg * 4 + wave;
     nvx_u32x4 a[KS];
     if (tile < n_tiles) {
         const nvx_u32x4* wt = wp + (int64_t)tile * KS * 64 + lane;
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void lmhead_sample_kernel(
         unsigned long long k64 = keys[tid];
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const unsigned long long o = keys[w * (MT * 16) + tid]; k64 = o > k64 ? o : k64; }
-        winners[(int64_t)blockIdx.x * m_rows + tid] = k64;
+        winners[(int64_t)wg * m_rows + tid] = k64;
     }
 }
 
@@ -235,8 +250,18 @@ __global__ __launch_bounds__(256, 1) void linear_stream_kernel(
 // per row: the best of the workgroups' keys, as a key and / or as a token id.  One wave per row: the keys of a row are
 // n_sets independent loads (a loop over them in one thread is n_sets memory round trips in a row).
 __global__ __launch_bounds__(64) void lmhead_pick_kernel(const unsigned long long* __restrict__ winners, int n_sets, int batch,
-                                                         unsigned long long* __restrict__ key_out, int64_t* __restrict__ out_ids) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+                                                         unsigned long long* __restrict__ key_out, int64_t* __restrict__ out_ids,
+                                                         int group_rows) {
+    // (a launch of two row groups left its keys group by group: n_sets sets of the group's rows each)
+    int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int out_row = row;
+    if (group_rows < batch) {
+        const int g = row / group_rows, first = g * group_rows;
+        winners += (int64_t)n_sets * first;
+        batch = g == 0 ? group_rows : batch - first;
+        row -= first;
+    }
     unsigned long long w = 0;
     for (int s0 = 0; s0 < n_sets; s0 += 64 * 4) {
         unsigned long long o[4];
@@ -248,8 +273,8 @@ __global__ __launch_bounds__(64) void lmhead_pick_kernel(const unsigned long lon
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) { const unsigned long long o = __shfl_xor(w, sh, 64); w = o > w ? o : w; }
     if (lane == 0) {
-        if (key_out) key_out[row] = w;
-        if (out_ids) out_ids[row] = w == 0 ? 0 : (int64_t)(0xffffffffu - (uint32_t)(w & 0xffffffffull));
+        if (key_out) key_out[out_row] = w;
+        if (out_ids) out_ids[out_row] = w == 0 ? 0 : (int64_t)(0xffffffffu - (uint32_t)(w & 0xffffffffull));
     }
 }
 
@@ -353,12 +378,16 @@ extern "C" int NVX_ENTRY(nvx_lmhead_sample)(const void* w_packed, int64_t n_rows
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MTV, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((lmhead_sample_kernel<MTV, 1024>), dim3((unsigned)grid), dim3(256), lds, st, (const nvx_u32x4*)w_packed,         \
                            (const uint16_t*)x + (int64_t)r0 * x_row_stride, x_row_stride, rows, r0, temperatures + r0, n_tiles,             \
-                           (int)vocab_offset, (int)end, seed, offset, (unsigned long long*)ws + (int64_t)grid * r0,                        \
-                           logits_out ? (uint16_t*)logits_out + (int64_t)r0 * logits_row_stride : (uint16_t*)nullptr, logits_row_stride);  \
+                           (int)vocab_offset, (int)end, seed, offset, (unsigned long long*)ws + (int64_t)(grid / groups) * r0,            \
+                           logits_out ? (uint16_t*)logits_out + (int64_t)r0 * logits_row_stride : (uint16_t*)nullptr, logits_row_stride,   \
+                           groups, per_pass);                                                                                              \
     } while (0)
-    for (int r0 = 0; r0 < (int)batch; r0 += per_pass) {
-        const int rows = (int)batch - r0 < per_pass ? (int)batch - r0 : per_pass;
-        switch ((rows + 15) / 16) {
+    // Two passes go out as ONE launch of two row groups on paired workgroups (see the kernel) where the grid allows the
+    // pairing; more passes follow one another.
+    const int groups = (passes == 2 && grid % 16 == 0) ? 2 : 1;
+    for (int r0 = 0; r0 < (int)batch; r0 += per_pass * groups) {
+        const int rows = groups == 2 ? (int)batch : ((int)batch - r0 < per_pass ? (int)batch - r0 : per_pass);
+        switch ((per_pass < rows ? per_pass + 15 : rows + 15) / 16) {
             case 1: NVX_LMH(1); break;
             case 2: NVX_LMH(2); break;
             case 3: NVX_LMH(3); break;
@@ -366,8 +395,9 @@ extern "C" int NVX_ENTRY(nvx_lmhead_sample)(const void* w_packed, int64_t n_rows
         }
         int rc = nvx_check_launch(who);
         if (rc) return rc;
-        hipLaunchKernelGGL(lmhead_pick_kernel, dim3((unsigned)rows), dim3(64), 0, st, (const unsigned long long*)ws + (int64_t)grid * r0, grid,
-                           rows, key_out ? (unsigned long long*)key_out + r0 : (unsigned long long*)nullptr, out_ids ? out_ids + r0 : nullptr);
+        hipLaunchKernelGGL(lmhead_pick_kernel, dim3((unsigned)rows), dim3(64), 0, st, (const unsigned long long*)ws + (int64_t)(grid / groups) * r0,
+                           grid / groups, rows, key_out ? (unsigned long long*)key_out + r0 : (unsigned long long*)nullptr,
+                           out_ids ? out_ids + r0 : nullptr, groups == 2 ? per_pass : rows);
         rc = nvx_check_launch("nvx_lmhead_sample(pick)");
         if (rc) return rc;
     }
