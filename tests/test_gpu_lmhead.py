@@ -89,6 +89,11 @@ def test_full_vocabulary_ragged_rows_greedy_rows_and_padding_tokens(ops):
     # a vocabulary that ends before the weight does (padding of a vocabulary split over ranks)
     _case(ops, 9, 1024, torch.bfloat16, 3, vocab=1001)
     _case(ops, 33, 2048, torch.float16, 4)
+    # 65..128 rows: two row groups in one launch on paired workgroups (full vocabulary: one workgroup per compute unit), and
+    # the same height where the grid cannot be paired (19 workgroups): one pass after the other
+    _case(ops, 100, 151936, torch.bfloat16, 5)
+    _case(ops, 70, 1200, torch.bfloat16, 6, temps=[0.6] * 35 + [0.0] * 35)
+    _case(ops, 128, 4096, torch.float16, 7)
 
 
 def test_shards_of_the_vocabulary_pick_the_token_of_the_whole_row(ops):
